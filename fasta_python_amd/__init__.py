@@ -1,0 +1,22 @@
+"""fasta_python_amd -- MI355X-native forward-backward splitting behind the fasta-python call surface.
+
+    from fasta_python_amd import fasta, Convergence, linalg, proximal, stopping, losses
+
+`fasta(A[, At], f, gradf, g, proxg, x0, ...)` keeps the reference's signature, options, defaults
+and `Convergence` record (reference: fasta/__init__.py:38-53, :323-351); the work runs in
+hand-written HIP kernels through the ctypes C ABI of include/fasta_hip.h.  The top-level `fasta`
+package in this repository re-exports these names so `import fasta` keeps working.
+
+No CPU fallback: importing works anywhere, but creating an operator or calling `fasta()` needs the
+built `libfasta_hip.so` and a gfx950 GPU, and raises otherwise.
+"""
+
+from . import hip, linalg, losses, proximal, stopping
+from .linalg import DenseMatrixMap, GradDivMap, LinearMap, LinearOperator
+from .losses import LeastSquares
+from .proximal import Box, L1Ball, LinfProx, NonNeg, NoProx, Shrink, TVDualBall
+from .solver import EPSILON, Convergence, FBSolver, fasta
+
+__all__ = ["fasta", "Convergence", "FBSolver", "EPSILON", "linalg", "proximal", "stopping", "losses", "hip",
+           "LinearMap", "LinearOperator", "DenseMatrixMap", "GradDivMap", "LeastSquares",
+           "Shrink", "NonNeg", "LinfProx", "L1Ball", "Box", "TVDualBall", "NoProx"]

@@ -1,0 +1,806 @@
+// fasta_hip.hip -- host side of libfasta_hip.so (C ABI declared in include/fasta_hip.h).
+// gfx950 only.  No PyTorch, no rocBLAS: every device operation is a kernel from fh_dense.h / fh_tv.h,
+// plus RCCL (dlopen'ed on first use) for the row-sharded adjoint.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+
+#include "../../include/fasta_hip.h"
+#include "fh_dense.h"
+#include "fh_tv.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code ? code : FH_E_ARG;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define FH_TRY(expr)          \
+  do {                        \
+    int r_ = (expr);          \
+    if (r_ != 0) return r_;   \
+  } while (0)
+
+extern "C" const char* fh_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// RCCL through dlopen (no link-time dependency; the single-GPU path never touches it)
+// ------------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } fh_nccl_uid;
+typedef void* fh_nccl_comm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(fh_nccl_uid*) = nullptr;
+  int (*CommInitRank)(fh_nccl_comm*, int, fh_nccl_uid, int) = nullptr;
+  int (*CommDestroy)(fh_nccl_comm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, fh_nccl_comm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static const int kNcclFloat64 = 8;   // ncclDouble
+static const int kNcclSum = 0;       // ncclSum
+
+static int rccl_load() {
+  if (g_rccl.lib) return 0;
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const char* nm : names) {
+    g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) return fail(FH_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+#define SYM(field, name)                                                      \
+  *(void**)(&g_rccl.field) = dlsym(g_rccl.lib, name);                         \
+  if (!g_rccl.field) return fail(FH_E_RCCL, "librccl lacks symbol %s", name)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  return 0;
+}
+#define NCCL_TRY(expr)                                                                        \
+  do {                                                                                        \
+    int r_ = (expr);                                                                          \
+    if (r_ != 0) return fail(20000 + r_, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+enum { OP_NONE = 0, OP_DENSE = 1, OP_STENCIL = 2 };
+
+struct fh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int op = OP_NONE;
+  uint64_t m = 0, n = 0;     // logical (local) rows / columns of A   (stencil: m = H*W, n = 2*H*W)
+  uint64_t mp = 0, ld = 0;   // padded rows, device leading dimension (dense)
+  uint64_t nv = 0, mv = 0;   // allocated n-side / m-side vector lengths (doubles)
+  uint64_t H = 0, W = 0;
+  double* A = nullptr;
+  // n-side
+  double* X[2] = {nullptr, nullptr};   // x0 / x1 (ping-pong)
+  double* P[2] = {nullptr, nullptr};   // prox outputs: x_accel1 / x_accel0
+  double* G[2] = {nullptr, nullptr};   // g0 / g1
+  double* xhat = nullptr;
+  double* best = nullptr;
+  double* T[4] = {nullptr, nullptr, nullptr, nullptr};
+  int xc = 0, pc = 0, gc = 0, zc = 0;
+  bool last_accel = false;
+  // m-side
+  double* b = nullptr;
+  double* Z[2] = {nullptr, nullptr};
+  double* zt = nullptr;
+  bool has_b = false;
+  // prox
+  int prox_kind = FH_PROX_IDENTITY;
+  double mu = 0.0, lo = 0.0, hi = 0.0;
+  // workspace
+  double* ws = nullptr;
+  size_t ws_bytes = 0;
+  unsigned* counters = nullptr;      // 4096 words, zeroed at creation; kernels leave them zero
+  double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
+  double* hscal = nullptr;           // pinned host mirror
+  // tuning
+  int fwd_rows = 8;
+  long long fwd_cap = 0;
+  int adj_slab = 0;
+  int adj_cpt = 2;
+  int ld_pad = 0;
+  int nt_loads = 1;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[FH_NKERNELS][2];
+  bool ev_pending[FH_NKERNELS] = {false, false, false, false};
+  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0};
+  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0};
+  // comm
+  fh_nccl_comm comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+static const int kCounterWords = 8192;
+enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_ADJ_CC = 16 };
+
+static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
+
+static int use_device(fh_ctx* c) {
+  HIP_TRY(hipSetDevice(c->device));
+  return 0;
+}
+
+static void free_operator(fh_ctx* c) {
+  auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  fr(c->A);
+  for (int i = 0; i < 2; ++i) { fr(c->X[i]); fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
+  fr(c->xhat); fr(c->best); fr(c->b); fr(c->zt);
+  for (int i = 0; i < 4; ++i) fr(c->T[i]);
+  fr(c->ws); c->ws_bytes = 0;
+  c->op = OP_NONE; c->has_b = false;
+}
+
+static int alloc_zero(fh_ctx* c, double** p, uint64_t elems) {
+  HIP_TRY(hipMalloc((void**)p, elems * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(*p, 0, elems * sizeof(double), c->stream));
+  return 0;
+}
+
+static int alloc_vectors(fh_ctx* c) {
+  // +16 slack doubles on the n-side so sharded runs can append scalars to the all-reduce buffer
+  for (int i = 0; i < 2; ++i) {
+    FH_TRY(alloc_zero(c, &c->X[i], c->nv + 16));
+    FH_TRY(alloc_zero(c, &c->P[i], c->nv + 16));
+    FH_TRY(alloc_zero(c, &c->G[i], c->nv + 16));
+    FH_TRY(alloc_zero(c, &c->Z[i], c->mv + 16));
+  }
+  FH_TRY(alloc_zero(c, &c->xhat, c->nv + 16));
+  FH_TRY(alloc_zero(c, &c->best, c->nv + 16));
+  for (int i = 0; i < 4; ++i) FH_TRY(alloc_zero(c, &c->T[i], c->nv + 16));
+  FH_TRY(alloc_zero(c, &c->b, c->mv + 16));
+  FH_TRY(alloc_zero(c, &c->zt, c->mv + 16));
+  c->xc = c->pc = c->gc = c->zc = 0;
+  return 0;
+}
+
+static int ensure_ws(fh_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return 0;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->ws) { HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+  bytes = round_up(bytes, 1 << 20);
+  HIP_TRY(hipMalloc((void**)&c->ws, bytes));
+  c->ws_bytes = bytes;
+  return 0;
+}
+
+// ---- timing helpers ------------------------------------------------------------------------------
+static inline void t_begin(fh_ctx* c, int k) {
+  if (c->timing) { (void)hipEventRecord(c->ev[k][0], c->stream); }
+}
+static inline void t_end(fh_ctx* c, int k) {
+  if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
+}
+static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending event pairs
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->timing) {
+    for (int k = 0; k < FH_NKERNELS; ++k) {
+      if (!c->ev_pending[k]) continue;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev[k][0], c->ev[k][1]));
+      c->tot_ms[k] += ms;
+      c->launches[k] += 1;
+      c->ev_pending[k] = false;
+    }
+  }
+  return 0;
+}
+
+static int fetch_scalars(fh_ctx* c, double* scalars) {
+  HIP_TRY(hipMemcpyAsync(c->hscal, c->dscal, FH_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  FH_TRY(finish(c));
+  if (scalars) memcpy(scalars, c->hscal, FH_NSCALARS * sizeof(double));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// library / context API
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_device_count(int* count) {
+  if (!count) return fail(FH_E_ARG, "fh_device_count: null pointer");
+  HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+extern "C" int fh_create(int device, fh_ctx** out) {
+  if (!out) return fail(FH_E_ARG, "fh_create: null out pointer");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(FH_E_ARG, "fh_create: device %d out of range (have %d)", device, ndev);
+  fh_ctx* c = new fh_ctx();
+  c->device = device;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMalloc((void**)&c->dscal, (FH_NSCALARS + 16) * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(c->dscal, 0, (FH_NSCALARS + 16) * sizeof(double), c->stream));
+  HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocDefault));
+  for (int k = 0; k < FH_NKERNELS; ++k) {
+    HIP_TRY(hipEventCreate(&c->ev[k][0]));
+    HIP_TRY(hipEventCreate(&c->ev[k][1]));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+extern "C" int fh_comm_destroy(fh_ctx* c);
+
+extern "C" int fh_destroy(fh_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)fh_comm_destroy(c);
+  free_operator(c);
+  if (c->counters) (void)hipFree(c->counters);
+  if (c->dscal) (void)hipFree(c->dscal);
+  if (c->hscal) (void)hipHostFree(c->hscal);
+  for (int k = 0; k < FH_NKERNELS; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int fh_sync(fh_ctx* c) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  FH_TRY(use_device(c));
+  return finish(c);
+}
+
+extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  switch (key) {
+    case FH_TUNE_FWD_ROWS:
+      if (value != 4 && value != 8 && value != 16) return fail(FH_E_ARG, "FWD_ROWS must be 4, 8 or 16");
+      c->fwd_rows = (int)value; return 0;
+    case FH_TUNE_FWD_GRID_CAP:
+      if (value < 0) return fail(FH_E_ARG, "FWD_GRID_CAP must be >= 0");
+      c->fwd_cap = value; return 0;
+    case FH_TUNE_ADJ_SLAB_ROWS:
+      if (value < 0 || value > ADJ_MAX_SLAB || value % 8) return fail(FH_E_ARG, "ADJ_SLAB_ROWS must be a multiple of 8 in [0,%d]", ADJ_MAX_SLAB);
+      c->adj_slab = (int)value; return 0;
+    case FH_TUNE_ADJ_CPT:
+      if (value != 1 && value != 2 && value != 4) return fail(FH_E_ARG, "ADJ_CPT must be 1, 2 or 4");
+      c->adj_cpt = (int)value; return 0;
+    case FH_TUNE_LD_PAD:
+      if (value < 0 || value % 16) return fail(FH_E_ARG, "LD_PAD must be a non-negative multiple of 16");
+      if (c->op != OP_NONE) return fail(FH_E_STATE, "LD_PAD must be set before the matrix");
+      c->ld_pad = (int)value; return 0;
+    case FH_TUNE_NT_LOADS:
+      c->nt_loads = value ? 1 : 0; return 0;
+    default: return fail(FH_E_ARG, "unknown tuning key %d", key);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator set-up
+// ------------------------------------------------------------------------------------------------
+static int setup_dense(fh_ctx* c, uint64_t m, uint64_t n) {
+  if (m == 0 || n == 0) return fail(FH_E_ARG, "matrix must be non-empty (got %llu x %llu)", (unsigned long long)m, (unsigned long long)n);
+  if (m >= (1ull << 31) || n >= (1ull << 31)) return fail(FH_E_ARG, "matrix dimension exceeds 2^31-1");
+  FH_TRY(use_device(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  free_operator(c);
+  c->m = m; c->n = n;
+  c->mp = round_up(m, 16);
+  c->ld = round_up(n, 16) + (uint64_t)c->ld_pad;
+  c->nv = c->ld; c->mv = c->mp;
+  HIP_TRY(hipMalloc((void**)&c->A, c->mp * c->ld * sizeof(double)));
+  FH_TRY(alloc_vectors(c));
+  c->op = OP_DENSE;
+  return 0;
+}
+
+extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n, uint64_t ld_host) {
+  if (!c || !A) return fail(FH_E_ARG, "fh_set_matrix: null argument");
+  if (ld_host < n) return fail(FH_E_ARG, "fh_set_matrix: ld_host %llu < n %llu", (unsigned long long)ld_host, (unsigned long long)n);
+  FH_TRY(setup_dense(c, m, n));
+  HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * sizeof(double), c->stream));
+  HIP_TRY(hipMemcpy2DAsync(c->A, c->ld * sizeof(double), A, ld_host * sizeof(double), n * sizeof(double), m,
+                           hipMemcpyHostToDevice, c->stream));
+  return finish(c);
+}
+
+extern "C" int fh_generate_matrix(fh_ctx* c, uint64_t m, uint64_t n, uint64_t row0, uint64_t seed, double coef) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  FH_TRY(setup_dense(c, m, n));
+  const uint64_t key = fh_mix(seed);
+  k_gen_matrix<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, c->ld, (uint32_t)(c->ld / 2), (uint32_t)m, (uint32_t)c->mp,
+                                                          (uint32_t)n, row0, key, coef);
+  HIP_TRY(hipGetLastError());
+  return finish(c);
+}
+
+extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, double* out) {
+  if (!c || !out) return fail(FH_E_ARG, "null argument");
+  if (c->op != OP_DENSE) return fail(FH_E_STATE, "no dense matrix set");
+  if (row0 + nrows > c->m) return fail(FH_E_ARG, "rows [%llu,%llu) out of range (m=%llu)", (unsigned long long)row0,
+                                       (unsigned long long)(row0 + nrows), (unsigned long long)c->m);
+  FH_TRY(use_device(c));
+  HIP_TRY(hipMemcpy2DAsync(out, c->n * sizeof(double), c->A + row0 * c->ld, c->ld * sizeof(double), c->n * sizeof(double),
+                           nrows, hipMemcpyDeviceToHost, c->stream));
+  return finish(c);
+}
+
+extern "C" int fh_set_stencil(fh_ctx* c, uint64_t H, uint64_t W) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  if (H < 1 || W < 1 || (W % 2) != 0) return fail(FH_E_ARG, "stencil needs H>=1 and even W>=2 (got %llu x %llu)", (unsigned long long)H, (unsigned long long)W);
+  if (H * W >= (1ull << 31)) return fail(FH_E_ARG, "image too large");
+  FH_TRY(use_device(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  free_operator(c);
+  c->H = H; c->W = W;
+  c->m = H * W; c->n = 2 * H * W;
+  c->mp = c->m; c->ld = c->n;
+  c->nv = round_up(c->n, 16); c->mv = round_up(c->m, 16);
+  FH_TRY(alloc_vectors(c));
+  c->op = OP_STENCIL;
+  return finish(c);
+}
+
+extern "C" int fh_shape(fh_ctx* c, uint64_t* m, uint64_t* n) {
+  if (!c || !m || !n) return fail(FH_E_ARG, "null argument");
+  if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  *m = c->m; *n = c->n;
+  return 0;
+}
+
+extern "C" int fh_set_loss_lsq(fh_ctx* c, const double* b, uint64_t len) {
+  if (!c || !b) return fail(FH_E_ARG, "null argument");
+  if (c->op == OP_NONE) return fail(FH_E_STATE, "set the operator before the loss");
+  if (len != c->m) return fail(FH_E_ARG, "b has %llu entries, operator has %llu rows", (unsigned long long)len, (unsigned long long)c->m);
+  FH_TRY(use_device(c));
+  HIP_TRY(hipMemcpyAsync(c->b, b, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->has_b = true;
+  return finish(c);
+}
+
+extern "C" int fh_set_prox(fh_ctx* c, int kind, double mu, double lo, double hi) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  if (kind < FH_PROX_IDENTITY || kind > FH_PROX_BOX) return fail(FH_E_ARG, "unknown prox kind %d", kind);
+  if (kind == FH_PROX_BOX && !(lo <= hi)) return fail(FH_E_ARG, "box prox needs lo <= hi");
+  c->prox_kind = kind; c->mu = mu; c->lo = lo; c->hi = hi;
+  return 0;
+}
+
+// ---- vector access --------------------------------------------------------------------------------
+static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
+  const bool acc = c->last_accel;
+  *len = c->n;
+  switch (which) {
+    case FH_VEC_X0: return c->X[c->xc];
+    case FH_VEC_G0: return c->G[c->gc];
+    case FH_VEC_XHAT: return c->xhat;
+    case FH_VEC_XPROX: return c->P[c->pc ^ 1];
+    case FH_VEC_X1: return acc ? c->X[c->xc ^ 1] : c->P[c->pc ^ 1];
+    case FH_VEC_G1: return c->G[c->gc ^ 1];
+    case FH_VEC_BEST: return c->best;
+    case FH_VEC_B: *len = c->m; return c->b;
+    case FH_VEC_Z: *len = c->m; return c->Z[c->zc ^ 1];
+    case FH_VEC_T0: case FH_VEC_T1: case FH_VEC_T2: case FH_VEC_T3: return c->T[which - FH_VEC_T0];
+    default: return nullptr;
+  }
+}
+
+extern "C" int fh_set_vector(fh_ctx* c, int which, const double* host, uint64_t len) {
+  if (!c || !host) return fail(FH_E_ARG, "null argument");
+  if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  uint64_t want = 0;
+  double* d = vec_ptr(c, which, &want);
+  if (!d) return fail(FH_E_ARG, "unknown vector id %d", which);
+  if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
+  FH_TRY(use_device(c));
+  HIP_TRY(hipMemcpyAsync(d, host, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (which == FH_VEC_B) c->has_b = true;
+  return finish(c);
+}
+
+extern "C" int fh_get_vector(fh_ctx* c, int which, double* host, uint64_t len) {
+  if (!c || !host) return fail(FH_E_ARG, "null argument");
+  if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  uint64_t want = 0;
+  double* d = vec_ptr(c, which, &want);
+  if (!d) return fail(FH_E_ARG, "unknown vector id %d", which);
+  if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
+  FH_TRY(use_device(c));
+  HIP_TRY(hipMemcpyAsync(host, d, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return finish(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel launchers
+// ------------------------------------------------------------------------------------------------
+static ProxP make_prox(fh_ctx* c, double tau) {
+  ProxP px;
+  px.kind = c->prox_kind;
+  px.thr = tau * c->mu;               // `t*self.mu`, examples/sparse_least_squares.py:44
+  px.lo = c->lo; px.hi = c->hi;
+  px.level = c->dscal + FH_NSCALARS;  // device scalar written by the level search
+  return px;
+}
+
+template <int R, int KIND>
+static void launch_fwd_rk(fh_ctx* c, const FwdP& p, unsigned grid) {
+  if (c->nt_loads) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fwd_dense<R, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+}
+template <int R>
+static void launch_fwd_r(fh_ctx* c, const FwdP& p, unsigned grid, int kind) {
+  switch (kind) {
+    case PX_PLAIN:  launch_fwd_rk<R, PX_PLAIN>(c, p, grid); break;
+    case PX_SHRINK: launch_fwd_rk<R, PX_SHRINK>(c, p, grid); break;
+    case PX_NONNEG: launch_fwd_rk<R, PX_NONNEG>(c, p, grid); break;
+    case PX_LINF:   launch_fwd_rk<R, PX_LINF>(c, p, grid); break;
+    case PX_L1BALL: launch_fwd_rk<R, PX_L1BALL>(c, p, grid); break;
+    case PX_BOX:    launch_fwd_rk<R, PX_BOX>(c, p, grid); break;
+    default:        launch_fwd_rk<R, PX_IDENTITY>(c, p, grid); break;
+  }
+}
+
+// z := A * (mode 0: prox(x0 - tau g0) ; mode 1: x0) on the dense operator
+static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
+                            double* xhat, double* xp, double* z, int sub_b) {
+  const int R = c->fwd_rows;
+  if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
+  FwdP p;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n;
+  p.nrg = (uint32_t)(c->mp / R);
+  p.nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
+  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp;
+  p.b = c->b; p.z = z; p.tau = tau; p.sub_b = sub_b;
+  p.px = make_prox(c, tau);
+  const int kind = mode == 0 ? c->prox_kind : (int)PX_PLAIN;
+  unsigned grid = std::max(p.nrg, mode == 0 ? p.nchunks : 1u);
+  if (c->fwd_cap > 0) grid = (unsigned)std::min<long long>(grid, c->fwd_cap);
+  const size_t need = ((size_t)p.nchunks * 8 + grid) * sizeof(double);
+  FH_TRY(ensure_ws(c, need));
+  p.red_n = c->ws; p.red_m = c->ws + (size_t)p.nchunks * 8;
+  p.counter = c->counters + CNT_FWD;
+  p.out = c->dscal;
+  t_begin(c, FH_K_FWD);
+  switch (R) {
+    case 4: launch_fwd_r<4>(c, p, grid, kind); break;
+    case 16: launch_fwd_r<16>(c, p, grid, kind); break;
+    default: launch_fwd_r<8>(c, p, grid, kind); break;
+  }
+  t_end(c, FH_K_FWD);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int CPT>
+static void launch_adj_c(fh_ctx* c, const AdjP& p, unsigned grid) {
+  if (c->nt_loads) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_adj_dense<CPT, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+}
+
+struct AdjIO {
+  const double* z; const double* zacc0; int sub_b; int accel; double coef; int mode; double tau;
+  const double* x0; const double* xp; const double* xacc0; const double* xhat; double* x1; double* g1;
+};
+
+static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
+  AdjP p;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
+  const int CPT = c->adj_cpt;
+  p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
+  uint32_t slab = (uint32_t)c->adj_slab;
+  if (slab == 0) {   // auto: aim for ~4096 workgroups, 32..1024 rows per slab
+    const uint64_t target_slabs = std::max<uint64_t>(1, 4096 / p.ncc);
+    uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
+    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, 32), 1024);
+  }
+  p.slab_rows = slab;
+  p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
+  if (p.ncc + CNT_ADJ_CC > (uint32_t)kCounterWords) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
+  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.accel = io.accel; p.coef = io.coef;
+  p.mode = io.mode; p.tau = io.tau;
+  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
+  const size_t gpart_elems = (size_t)p.nslab * c->ld;
+  const size_t need = (gpart_elems + (size_t)p.ncc * 8 + p.nslab) * sizeof(double);
+  FH_TRY(ensure_ws(c, need));
+  p.gpart = c->ws; p.red_bb = c->ws + gpart_elems; p.red_f = p.red_bb + (size_t)p.ncc * 8;
+  p.cc_counter = c->counters + CNT_ADJ_CC; p.fin_counter = c->counters + CNT_ADJ_FIN;
+  p.out = c->dscal;
+  const unsigned grid = p.ncc * p.nslab;
+  t_begin(c, FH_K_ADJ);
+  switch (CPT) {
+    case 1: launch_adj_c<1>(c, p, grid); break;
+    case 4: launch_adj_c<4>(c, p, grid); break;
+    default: launch_adj_c<2>(c, p, grid); break;
+  }
+  t_end(c, FH_K_ADJ);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// sharded adjoint tail: sum g1 (+ the local ||r||^2) over ranks, then the n-side epilogue
+static int allreduce_and_epilogue(fh_ctx* c, const AdjIO& io) {
+  t_begin(c, FH_K_COMM);
+  NCCL_TRY(g_rccl.GroupStart());
+  NCCL_TRY(g_rccl.AllReduce(io.g1, io.g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
+  NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ_ADJ, c->dscal + FH_S_FSQ_ADJ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+  NCCL_TRY(g_rccl.GroupEnd());
+  t_end(c, FH_K_COMM);
+  if (io.mode != 0) return 0;
+  AdjP p;
+  memset(&p, 0, sizeof(p));
+  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n;
+  p.accel = io.accel; p.coef = io.coef; p.mode = 0; p.tau = io.tau;
+  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
+  const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
+  FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
+  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
+  t_begin(c, FH_K_AUX);
+  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, c->dscal + FH_S_FSQ_ADJ);
+  t_end(c, FH_K_AUX);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// sum|x_i| and max|x_i| of an n-length device vector -> dscal[GSUM], dscal[GMAX]  (g(x0) for objective_hist[0], :143)
+static int launch_gterms(fh_ctx* c, const double* x) {
+  const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 1024);
+  FH_TRY(ensure_ws(c, (size_t)grid * 2 * sizeof(double)));
+  t_begin(c, FH_K_AUX);
+  k_gterms<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(x, (uint32_t)c->n, c->ws, c->counters + CNT_AUX, c->dscal);
+  t_end(c, FH_K_AUX);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_level_search(fh_ctx* c, double tau) {
+  (void)tau;
+  return fail(FH_E_STATE, "LINF / L1BALL prox: level search not built yet");
+}
+
+static int launch_fwd_tv(fh_ctx* c, int, double, const double*, const double*, const double*, double*, double*, double*, int) {
+  (void)c; return fail(FH_E_STATE, "stencil operator kernels not built yet");
+}
+static int launch_adj_tv(fh_ctx* c, const AdjIO&) {
+  (void)c; return fail(FH_E_STATE, "stencil operator kernels not built yet");
+}
+
+// ---- operator-generic wrappers ---------------------------------------------------------------------
+static int op_fwd(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
+                  double* xhat, double* xp, double* z, int sub_b) {
+  if (c->op == OP_DENSE) return launch_fwd_dense(c, mode, tau, x0, g0, xacc0, xhat, xp, z, sub_b);
+  if (c->op == OP_STENCIL) return launch_fwd_tv(c, mode, tau, x0, g0, xacc0, xhat, xp, z, sub_b);
+  return fail(FH_E_STATE, "no operator set");
+}
+
+static int op_adj(fh_ctx* c, const AdjIO& io_in) {
+  AdjIO io = io_in;
+  const bool sharded = c->comm != nullptr;
+  if (sharded && c->op != OP_DENSE) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+  if (sharded && io.mode == 0) io.mode = 2;
+  if (c->op == OP_DENSE) FH_TRY(launch_adj_dense(c, io));
+  else if (c->op == OP_STENCIL) FH_TRY(launch_adj_tv(c, io));
+  else return fail(FH_E_STATE, "no operator set");
+  if (sharded) { io.mode = io_in.mode; FH_TRY(allreduce_and_epilogue(c, io)); }
+  return 0;
+}
+
+static int reduce_fsq_over_ranks(fh_ctx* c) {
+  if (!c->comm) return 0;
+  t_begin(c, FH_K_COMM);
+  NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+  t_end(c, FH_K_COMM);
+  return 0;
+}
+
+static int check_ready(fh_ctx* c, bool need_b) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set (call fh_set_matrix / fh_generate_matrix / fh_set_stencil)");
+  if (need_b && !c->has_b) return fail(FH_E_STATE, "no loss set (call fh_set_loss_lsq)");
+  return use_device(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver steps
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_init(fh_ctx* c, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  double* x0 = c->X[c->xc];
+  // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
+  FH_TRY(op_fwd(c, 1, 0.0, x0, nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 1));
+  FH_TRY(reduce_fsq_over_ranks(c));
+  AdjIO io = {c->Z[c->zc], nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->G[c->gc]};
+  FH_TRY(op_adj(c, io));
+  // x_accel1 := x0, best := x0 ; g(x0) terms for objective_hist[0] (:143) come from the host wrapper via FH_VEC ops
+  HIP_TRY(hipMemcpyAsync(c->P[c->pc], x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->best, x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  c->last_accel = false;
+  FH_TRY(launch_gterms(c, x0));
+  return fetch_scalars(c, scalars);
+}
+
+extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec) {
+  FH_TRY(check_ready(c, true));
+  uint64_t l1 = 0, l2 = 0;
+  double* src = vec_ptr(c, src_vec, &l1);
+  double* dst = vec_ptr(c, dst_vec, &l2);
+  if (!src || !dst || l1 != c->n || l2 != c->n) return fail(FH_E_ARG, "fh_gradient_at needs two n-length vectors");
+  FH_TRY(op_fwd(c, 1, 0.0, src, nullptr, nullptr, nullptr, nullptr, c->zt, 1));
+  AdjIO io = {c->zt, nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, dst};
+  FH_TRY(op_adj(c, io));
+  return finish(c);
+}
+
+extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
+  FH_TRY(check_ready(c, false));
+  if (!out) return fail(FH_E_ARG, "null out");
+  uint64_t l1 = 0, l2 = 0;
+  double* a = vec_ptr(c, vec_a, &l1);
+  double* b = vec_ptr(c, vec_b, &l2);
+  if (!a || !b || l1 != l2) return fail(FH_E_ARG, "fh_diff_norm needs two vectors of equal length");
+  const unsigned grid = (unsigned)std::min<uint64_t>((l1 + FH_WG - 1) / FH_WG, 1024);
+  FH_TRY(ensure_ws(c, grid * sizeof(double)));
+  k_diff_sq<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(a, b, (uint32_t)l1, c->ws, c->counters + CNT_AUX, c->dscal + FH_NSCALARS + 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->hscal + FH_NSCALARS + 1, c->dscal + FH_NSCALARS + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  FH_TRY(finish(c));
+  *out = sqrt(c->hscal[FH_NSCALARS + 1]);
+  return 0;
+}
+
+extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
+  FH_TRY(op_fwd(c, 0, tau, c->X[c->xc], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
+  FH_TRY(reduce_fsq_over_ranks(c));
+  return fetch_scalars(c, scalars);
+}
+
+extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  AdjIO io;
+  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
+  io.mode = 0; io.tau = tau;
+  io.x0 = c->X[c->xc]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+  io.x1 = c->X[c->xc ^ 1]; io.g1 = c->G[c->gc ^ 1];
+  c->last_accel = accel != 0;
+  FH_TRY(op_adj(c, io));
+  return fetch_scalars(c, scalars);
+}
+
+extern "C" int fh_commit(fh_ctx* c, int save_best) {
+  FH_TRY(check_ready(c, false));
+  if (c->last_accel) {
+    c->xc ^= 1;   // x0 <- extrapolated x1 (X ping-pong)
+    c->pc ^= 1;   // x_accel0 <- this iteration's prox output (P ping-pong)
+  } else {
+    // x1 is the prox output itself: adopt its buffer as x0; the old x0 buffer becomes the next prox target
+    std::swap(c->X[c->xc], c->P[c->pc ^ 1]);
+  }
+  c->zc ^= 1;     // z_accel0 <- z1
+  c->gc ^= 1;     // g0 <- g1
+  if (save_best)
+    HIP_TRY(hipMemcpyAsync(c->best, c->X[c->xc], c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int fh_apply(fh_ctx* c, int adjoint, const double* in, double* out) {
+  FH_TRY(check_ready(c, false));
+  if (!in || !out) return fail(FH_E_ARG, "null argument");
+  if (!adjoint) {
+    HIP_TRY(hipMemcpyAsync(c->T[3], in, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FH_TRY(op_fwd(c, 1, 0.0, c->T[3], nullptr, nullptr, nullptr, nullptr, c->zt, 0));
+    HIP_TRY(hipMemcpyAsync(out, c->zt, c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->zt, in, c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    AdjIO io = {c->zt, nullptr, 0, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->T[3]};
+    FH_TRY(op_adj(c, io));
+    HIP_TRY(hipMemcpyAsync(out, c->T[3], c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  return finish(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row sharding
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_comm_unique_id(void* id128) {
+  if (!id128) return fail(FH_E_ARG, "null id buffer");
+  FH_TRY(rccl_load());
+  fh_nccl_uid id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) {
+  if (!c || !id128) return fail(FH_E_ARG, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(FH_E_ARG, "bad rank %d of %d", rank, nranks);
+  FH_TRY(rccl_load());
+  FH_TRY(use_device(c));
+  if (c->comm) FH_TRY(fh_comm_destroy(c));
+  fh_nccl_uid id;
+  memcpy(&id, id128, sizeof(id));
+  NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  c->nranks = nranks; c->rank = rank;
+  return 0;
+}
+
+extern "C" int fh_comm_destroy(fh_ctx* c) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  if (c->comm) {
+    (void)hipStreamSynchronize(c->stream);
+    NCCL_TRY(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->nranks = 1; c->rank = 0;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+extern "C" int fh_timing_enable(fh_ctx* c, int on) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  c->timing = on != 0;
+  return 0;
+}
+extern "C" int fh_timing_get(fh_ctx* c, int k, double* total_ms, uint64_t* launches) {
+  if (!c || k < 0 || k >= FH_NKERNELS) return fail(FH_E_ARG, "bad kernel id");
+  if (total_ms) *total_ms = c->tot_ms[k];
+  if (launches) *launches = c->launches[k];
+  return 0;
+}
+extern "C" int fh_timing_reset(fh_ctx* c) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  for (int k = 0; k < FH_NKERNELS; ++k) { c->tot_ms[k] = 0; c->launches[k] = 0; c->ev_pending[k] = false; }
+  return 0;
+}
+
+extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint64_t* bytes_per_pass) {
+  FH_TRY(check_ready(c, false));
+  if (c->op != OP_DENSE) return fail(FH_E_STATE, "stream-read ceiling needs a dense matrix");
+  if (reps < 1) reps = 1;
+  const uint64_t n2 = c->mp * c->ld / 2;
+  k_stream_read<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, n2, c->dscal + FH_NSCALARS + 2);   // warm-up
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; ++i)
+    k_stream_read<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, n2, c->dscal + FH_NSCALARS + 2);
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_per_pass) *ms_per_pass = ms / reps;
+  if (bytes_per_pass) *bytes_per_pass = n2 * 16;
+  return 0;
+}

@@ -1,0 +1,474 @@
+// fh_dense.h -- fused dense-matrix FBS kernels for gfx950.
+//
+// Device layout of A: row-major float64, `mp` rows (m padded with zero rows to a multiple of 16) of
+// `ld` doubles (n padded with zero columns to a multiple of 16, plus an optional anti-aliasing pad),
+// so every row starts 128-byte aligned and every lane issues 16-byte loads with no tail logic.
+// n-side vectors are `ld` long with zero padding; m-side vectors are `mp` long with zero padding.
+//
+//   K-fwd  (k_fwd_dense):  one launch =  xhat = x0 - tau*g0 ; xprox = prox(xhat) ; z1 = A xprox ;
+//                          ||z1-b||^2, <Dx,g0>, ||Dx||^2, ||xprox-xhat||^2, ||g0||^2, g terms, restart dot.
+//       Each workgroup owns R whole rows per pass: lanes stride the row in 16-byte pieces
+//       (4 KiB contiguous per workgroup per row), recompute the prox'd x chunk on the fly from
+//       x0/g0 (1 MiB, L2 resident), keep R accumulators, then wave-__shfl + LDS reduce.
+//       Algorithmic HBM bytes: m*n*8 (A) + (2n + m) reads + (2n + m) writes.
+//   K-adj  (k_adj_dense):  one launch =  r = z1' - b ; g1 = A^T r ; Dg, <Dx,Dg>, ||Dg||^2 (+ FISTA
+//                          extrapolation of x and z).
+//       Workgroup (slab, column chunk): lanes own 16-byte column pairs, walk down the slab's rows
+//       with per-column register accumulators (coalesced row pieces of the same row-major bytes),
+//       r staged in LDS.  Slab partials go to a workspace; the LAST workgroup to finish a column
+//       chunk sums the slabs in index order and does the n-side epilogue; the last chunk finaliser
+//       sums the scalars.  No float atomics => bitwise repeatable.
+//       Algorithmic HBM bytes: m*n*8 (A) + (2m [+m]) + 4n reads + n [+n] writes (+ partials, <0.2 %).
+#pragma once
+#include "fh_device.h"
+
+struct FwdP {
+  const double* A;
+  uint64_t ld;          // doubles per device row
+  uint32_t ld2;         // ld / 2  (16-byte pieces per row)
+  uint32_t n;           // logical columns
+  uint32_t nrg;         // row groups = mp / R
+  uint32_t nchunks;     // ceil(ld2 / 256)
+  const double* x0; const double* g0; const double* xacc0;
+  double* xhat; double* xp;
+  const double* b; double* z;
+  double tau;
+  int sub_b;            // residual r = z - b (1) or r = z (0, fh_apply)
+  ProxP px;
+  double* red_n;        // [nchunks][8]
+  double* red_m;        // [gridDim.x]
+  unsigned* counter;
+  double* out;          // device scalar block (FH_S_* layout)
+};
+
+// scalar slots (mirror include/fasta_hip.h enum fh_scalar)
+enum { S_FSQ = 0, S_DXG0 = 1, S_DX2 = 2, S_XH2 = 3, S_G02 = 4, S_GSUM = 5, S_GMAX = 6, S_RDOT = 7,
+       S_DXDG = 8, S_DG2 = 9, S_FSQ_ADJ = 10, S_XH2_ADJ = 11, S_GSUM_ADJ = 12, S_GMAX_ADJ = 13, S_ALPHA = 14 };
+
+// Reduce K running values over the workgroup; slot `maxslot` (or -1) uses max instead of +.
+// Result valid in thread 0.  `scr` = 4*K doubles of LDS.
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* scr, int maxslot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    v[k] = (k == maxslot) ? wave_max(v[k]) : wave_sum(v[k]);
+    if (lane == 0) scr[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k == maxslot) v[k] = fmax(fmax(scr[k], scr[K + k]), fmax(scr[2 * K + k], scr[3 * K + k]));
+      else v[k] = ((scr[k] + scr[K + k]) + scr[2 * K + k]) + scr[3 * K + k];
+    }
+  }
+  __syncthreads();
+}
+
+// xprox pair for 16-byte piece c.  KIND = PX_PLAIN: xprox := x0 (fh_init / fh_apply / Lipschitz probes).
+template <int KIND>
+__device__ __forceinline__ d2 xprox_pair(const FwdP& p, uint32_t c, double level) {
+  d2 xv = reinterpret_cast<const d2*>(p.x0)[c];
+  if (KIND != PX_PLAIN) {
+    const d2 gv = reinterpret_cast<const d2*>(p.g0)[c];
+    xv.x = prox_scalar<KIND>(fwd_point(xv.x, gv.x, p.tau), p.px, level);
+    xv.y = prox_scalar<KIND>(fwd_point(xv.y, gv.y, p.tau), p.px, level);
+  }
+  return xv;
+}
+
+template <int R, int NT, int KIND>
+__global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 16];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
+
+  // ---------------- n-side: forward point, prox, line-search reductions (once per column) --------
+  if (KIND != PX_PLAIN) {
+    for (uint32_t chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
+      const uint32_t c = chunk * FH_WG + tid;
+      double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax, rdot
+      if (c < p.ld2) {
+        const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
+        const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
+        d2 xav = {0.0, 0.0};
+        if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[c];
+        d2 xh, xp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool valid = (2u * c + e) < p.n;
+          const double x0e = x0v[e], g0e = g0v[e];
+          double xhe = fwd_point(x0e, g0e, p.tau);
+          double xpe = prox_scalar<KIND>(xhe, p.px, level);
+          if (!valid) { xhe = 0.0; xpe = 0.0; }
+          xh[e] = xhe; xp[e] = xpe;
+          if (valid) {
+            const double dx = sub_nofma(xpe, x0e);
+            const double dh = sub_nofma(xpe, xhe);
+            v[0] = fma(dx, g0e, v[0]);
+            v[1] = fma(dx, dx, v[1]);
+            v[2] = fma(dh, dh, v[2]);
+            v[3] = fma(g0e, g0e, v[3]);
+            v[4] += fabs(xpe);
+            v[5] = fmax(v[5], fabs(xpe));
+            v[6] = fma(sub_nofma(x0e, xpe), sub_nofma(xpe, xav[e]), v[6]);
+          }
+        }
+        reinterpret_cast<d2*>(p.xhat)[c] = xh;
+        reinterpret_cast<d2*>(p.xp)[c] = xp;
+      }
+      block_reduce<7>(v, s_scr, 5);
+      if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) p.red_n[(uint64_t)chunk * 8 + 1 + k] = v[k];
+      }
+    }
+  }
+
+  // ---------------- m-side: z1 = A xprox for R rows per pass ----------------------------------
+  // Two 16-byte pieces per lane per trip: the 2R row loads are issued first, the (L2-resident)
+  // x0/g0 loads and the prox recompute overlap their latency.
+  double fpart = 0.0;
+  const uint32_t ntrip = (p.ld2 + 2 * FH_WG - 1) / (2 * FH_WG);
+  for (uint32_t rg = blockIdx.x; rg < p.nrg; rg += gridDim.x) {
+    const d2* Ab = reinterpret_cast<const d2*>(p.A + (uint64_t)rg * R * p.ld);
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (uint32_t t = 0; t < ntrip; ++t) {
+      const uint32_t c0 = t * (2 * FH_WG) + tid;          // always < ld2 except possibly in the last trip
+      const uint32_t c1 = c0 + FH_WG;
+      const bool ok0 = c0 < p.ld2, ok1 = c1 < p.ld2;
+      const uint32_t k0 = ok0 ? c0 : 0u, k1 = ok1 ? c1 : 0u;   // clamp: in-bounds redundant loads
+      d2 a0[R], a1[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a0[r] = load_stream<NT>(Ab + (uint64_t)r * p.ld2 + k0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) a1[r] = load_stream<NT>(Ab + (uint64_t)r * p.ld2 + k1);
+      d2 x0v = xprox_pair<KIND>(p, k0, level);
+      d2 x1v = xprox_pair<KIND>(p, k1, level);
+      if (!ok0) x0v = (d2){0.0, 0.0};
+      if (!ok1) x1v = (d2){0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        acc[r] = fma(a0[r].x, x0v.x, acc[r]);
+        acc[r] = fma(a0[r].y, x0v.y, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        acc[r] = fma(a1[r].x, x1v.x, acc[r]);
+        acc[r] = fma(a1[r].y, x1v.y, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      acc[r] = wave_sum(acc[r]);
+      if (lane == 0) s_scr[wave * 16 + r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < R) {
+      const double zv = ((s_scr[tid] + s_scr[16 + tid]) + s_scr[32 + tid]) + s_scr[48 + tid];
+      const uint32_t row = rg * R + tid;
+      p.z[row] = zv;
+      const double rv = p.sub_b ? sub_nofma(zv, p.b[row]) : zv;
+      fpart = fma(rv, rv, fpart);
+    }
+    __syncthreads();
+  }
+  {
+    double v[1] = {fpart};
+    block_reduce<1>(v, s_scr, -1);
+    if (tid == 0) p.red_m[blockIdx.x] = v[0];
+  }
+
+  // ---------------- last workgroup: ordered final sums ------------------------------------------
+  if (arrive_last(p.counter, gridDim.x, s_flag)) {
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = tid; i < gridDim.x; i += FH_WG) v[0] += p.red_m[i];
+    if (KIND != PX_PLAIN) {
+      for (uint32_t i = tid; i < p.nchunks; i += FH_WG) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+          const double t = p.red_n[(uint64_t)i * 8 + k];
+          if (k == S_GMAX) v[k] = fmax(v[k], t); else v[k] += t;
+        }
+      }
+    }
+    block_reduce<8>(v, s_scr, S_GMAX);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p.out[k] = v[k];
+      p.out[S_ALPHA] = level;
+      __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AdjP {
+  const double* A;
+  uint64_t ld;
+  uint32_t ld2;
+  uint32_t n;
+  uint32_t mp;          // padded rows
+  uint32_t slab_rows;   // rows per slab (multiple of 8, <= ADJ_MAX_SLAB)
+  uint32_t nslab, ncc;
+  const double* z; const double* zacc0; const double* b;
+  int sub_b;            // r = z - b, else r = z
+  int accel;            // extrapolate z and x with `coef`
+  double coef;
+  int mode;             // 0 = FBS (BB epilogue), 1 = plain gradient (g1 only), 2 = sharded (g1 partial + local fsq only)
+  double tau;
+  const double* x0; const double* xp; const double* xacc0; const double* xhat;
+  double* x1;           // extrapolated iterate (accel only; else == xp and not written)
+  double* g1;
+  double* gpart;        // [nslab][ld]
+  double* red_bb;       // [ncc][8]
+  double* red_f;        // [nslab]
+  unsigned* cc_counter; // [ncc]
+  unsigned* fin_counter;
+  double* out;
+};
+
+#define ADJ_MAX_SLAB 2048
+
+// n-side epilogue for one element: BB terms and (optionally) FISTA extrapolation.
+// v: dxdg, dg2, xh2, gsum, gmax
+__device__ __forceinline__ double bb_element(const AdjP& p, double g1, double x0, double xp, double xacc0,
+                                             double xhat, bool valid, double (&v)[5]) {
+  double x1 = xp;
+  if (p.accel) x1 = extrapolate(xp, xacc0, p.coef);
+  if (valid) {
+    const double dx = sub_nofma(xp, x0);
+    const double dg = bb_dgrad(g1, xhat, x0, p.tau);
+    const double dh = sub_nofma(x1, xhat);
+    v[0] = fma(dx, dg, v[0]);
+    v[1] = fma(dg, dg, v[1]);
+    v[2] = fma(dh, dh, v[2]);
+    v[3] += fabs(x1);
+    v[4] = fmax(v[4], fabs(x1));
+  } else {
+    x1 = 0.0;
+  }
+  return x1;
+}
+
+template <int CPT, int NT>
+__global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
+  __shared__ __attribute__((aligned(16))) double s_r[ADJ_MAX_SLAB];
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t cc = blockIdx.x % p.ncc, slab = blockIdx.x / p.ncc;
+  const uint32_t row0 = slab * p.slab_rows;
+  const uint32_t rows = min(p.slab_rows, p.mp - row0);
+
+  // ---- stage the slab's residual r = z1' - b in LDS (z1' = extrapolated z when accelerating) ----
+  double fs = 0.0;
+  for (uint32_t i = tid; i < rows; i += FH_WG) {
+    double zv = p.z[row0 + i];
+    if (p.accel) zv = extrapolate(zv, p.zacc0[row0 + i], p.coef);
+    const double rv = p.sub_b ? sub_nofma(zv, p.b[row0 + i]) : zv;
+    s_r[i] = rv;
+    fs = fma(rv, rv, fs);
+  }
+  __syncthreads();
+
+  // ---- stream the slab: per-column accumulators, rows walked top to bottom ------------------------
+  uint32_t col[CPT];
+  d2 acc[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    col[j] = min(cc * (FH_WG * CPT) + j * FH_WG + tid, p.ld2 - 1u);   // clamp: redundant but in-bounds
+    acc[j] = (d2){0.0, 0.0};
+  }
+  const d2* Ab = reinterpret_cast<const d2*>(p.A) + (uint64_t)row0 * p.ld2;
+#pragma unroll 4
+  for (uint32_t i = 0; i < rows; ++i) {
+    const double rv = s_r[i];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const d2 a = load_stream<NT>(Ab + col[j]);
+      acc[j].x = fma(a.x, rv, acc[j].x);
+      acc[j].y = fma(a.y, rv, acc[j].y);
+    }
+    Ab += p.ld2;
+  }
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
+    if (c < p.ld2) reinterpret_cast<d2*>(p.gpart)[(uint64_t)slab * p.ld2 + c] = acc[j];
+  }
+  if (cc == 0) {
+    double v[1] = {fs};
+    block_reduce<1>(v, s_scr, -1);
+    if (tid == 0) p.red_f[slab] = v[0];
+  }
+
+  // ---- last workgroup of this column chunk: ordered slab sum + n-side epilogue ---------------------
+  if (!arrive_last(p.cc_counter + cc, p.nslab, s_flag)) return;
+  if (tid == 0) __hip_atomic_store(p.cc_counter + cc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  double v[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
+    if (c >= p.ld2) continue;
+    const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
+    d2 g = {0.0, 0.0};
+#pragma unroll 4
+    for (uint32_t s = 0; s < p.nslab; ++s) g += gp[(uint64_t)s * p.ld2];
+    reinterpret_cast<d2*>(p.g1)[c] = g;
+    if (p.mode == 0) {
+      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
+      const d2 xpv = reinterpret_cast<const d2*>(p.xp)[c];
+      const d2 xhv = reinterpret_cast<const d2*>(p.xhat)[c];
+      d2 xav = {0.0, 0.0};
+      if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[c];
+      d2 x1v;
+      x1v.x = bb_element(p, g.x, x0v.x, xpv.x, xav.x, xhv.x, 2u * c < p.n, v);
+      x1v.y = bb_element(p, g.y, x0v.y, xpv.y, xav.y, xhv.y, 2u * c + 1u < p.n, v);
+      if (p.accel) reinterpret_cast<d2*>(p.x1)[c] = x1v;
+    }
+  }
+  block_reduce<5>(v, s_scr, 4);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p.red_bb[(uint64_t)cc * 8 + k] = v[k];
+  }
+
+  // ---- last column-chunk finaliser: ordered scalar sums ------------------------------------------
+  if (!arrive_last(p.fin_counter, p.ncc, s_flag)) return;
+  double w[6] = {0, 0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax, fsq
+  for (uint32_t i = tid; i < p.ncc; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double t = p.red_bb[(uint64_t)i * 8 + k];
+      if (k == 4) w[k] = fmax(w[k], t); else w[k] += t;
+    }
+  }
+  for (uint32_t i = tid; i < p.nslab; i += FH_WG) w[5] += p.red_f[i];
+  block_reduce<6>(w, s_scr, 4);
+  if (tid == 0) {
+    p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
+    p.out[S_GSUM_ADJ] = w[3]; p.out[S_GMAX_ADJ] = w[4]; p.out[S_FSQ_ADJ] = w[5];
+    __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// n-side epilogue as its own launch: used after the RCCL all-reduce when A is row-sharded
+// (g1 already holds the global sum).  grid = nchunks workgroups of 256 column pairs.
+__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p, uint32_t nchunks, const double* fsq_src) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t c = blockIdx.x * FH_WG + tid;
+  double v[5] = {0, 0, 0, 0, 0};
+  if (c < p.ld2) {
+    const d2 g = reinterpret_cast<const d2*>(p.g1)[c];
+    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
+    const d2 xpv = reinterpret_cast<const d2*>(p.xp)[c];
+    const d2 xhv = reinterpret_cast<const d2*>(p.xhat)[c];
+    d2 xav = {0.0, 0.0};
+    if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[c];
+    d2 x1v;
+    x1v.x = bb_element(p, g.x, x0v.x, xpv.x, xav.x, xhv.x, 2u * c < p.n, v);
+    x1v.y = bb_element(p, g.y, x0v.y, xpv.y, xav.y, xhv.y, 2u * c + 1u < p.n, v);
+    if (p.accel) reinterpret_cast<d2*>(p.x1)[c] = x1v;
+  }
+  block_reduce<5>(v, s_scr, 4);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p.red_bb[(uint64_t)blockIdx.x * 8 + k] = v[k];
+  }
+  if (!arrive_last(p.fin_counter, nchunks, s_flag)) return;
+  double w[5] = {0, 0, 0, 0, 0};
+  for (uint32_t i = tid; i < nchunks; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double t = p.red_bb[(uint64_t)i * 8 + k];
+      if (k == 4) w[k] = fmax(w[k], t); else w[k] += t;
+    }
+  }
+  block_reduce<5>(w, s_scr, 4);
+  if (tid == 0) {
+    p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
+    p.out[S_GSUM_ADJ] = w[3]; p.out[S_GMAX_ADJ] = w[4];
+    p.out[S_FSQ_ADJ] = *fsq_src;
+    __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---- utility kernels ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FH_WG) void k_gen_matrix(double* A, uint64_t ld, uint32_t ld2, uint32_t m, uint32_t mp,
+                                                      uint32_t n, uint64_t row0, uint64_t key, double coef) {
+  const uint64_t total = (uint64_t)mp * ld2;
+  for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < total; t += (uint64_t)gridDim.x * FH_WG) {
+    const uint32_t row = (uint32_t)(t / ld2), c = (uint32_t)(t % ld2);
+    d2 v = {0.0, 0.0};
+    if (row < m) {
+      const uint64_t base = (row0 + row) * (uint64_t)n;
+      if (2u * c < n) v.x = fh_ihall(key, base + 2u * c, coef);
+      if (2u * c + 1u < n) v.y = fh_ihall(key, base + 2u * c + 1u, coef);
+    }
+    reinterpret_cast<d2*>(A)[t] = v;
+  }
+}
+
+// sum of (a-b)^2 over len elements -> out[0]; single-workgroup-final pattern
+__global__ __launch_bounds__(FH_WG) void k_diff_sq(const double* a, const double* b, uint32_t len, double* red,
+                                                   unsigned* counter, double* out) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  double v[1] = {0.0};
+  for (uint32_t i = blockIdx.x * FH_WG + threadIdx.x; i < len; i += gridDim.x * FH_WG) {
+    const double d = sub_nofma(a[i], b[i]);
+    v[0] = fma(d, d, v[0]);
+  }
+  block_reduce<1>(v, s_scr, -1);
+  if (threadIdx.x == 0) red[blockIdx.x] = v[0];
+  if (!arrive_last(counter, gridDim.x, s_flag)) return;
+  double w[1] = {0.0};
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) w[0] += red[i];
+  block_reduce<1>(w, s_scr, -1);
+  if (threadIdx.x == 0) {
+    out[0] = w[0];
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// sum|x| and max|x| over len elements -> out[S_GSUM], out[S_GMAX]
+__global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len, double* red, unsigned* counter, double* out) {
+  __shared__ __attribute__((aligned(16))) double s_scr[8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  double v[2] = {0.0, 0.0};
+  for (uint32_t i = blockIdx.x * FH_WG + threadIdx.x; i < len; i += gridDim.x * FH_WG) {
+    const double a = fabs(x[i]);
+    v[0] += a;
+    v[1] = fmax(v[1], a);
+  }
+  block_reduce<2>(v, s_scr, 1);
+  if (threadIdx.x == 0) { red[2 * blockIdx.x] = v[0]; red[2 * blockIdx.x + 1] = v[1]; }
+  if (!arrive_last(counter, gridDim.x, s_flag)) return;
+  double w[2] = {0.0, 0.0};
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) { w[0] += red[2 * i]; w[1] = fmax(w[1], red[2 * i + 1]); }
+  block_reduce<2>(w, s_scr, 1);
+  if (threadIdx.x == 0) {
+    out[S_GSUM] = w[0]; out[S_GMAX] = w[1];
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// read-only streaming pass over A (the "achievable ceiling" next to the 8 TB/s spec peak)
+__global__ __launch_bounds__(FH_WG) void k_stream_read(const double* A, uint64_t n2, double* sink) {
+  const d2* p = reinterpret_cast<const d2*>(A);
+  d2 acc = {0.0, 0.0};
+  const uint64_t stride = (uint64_t)gridDim.x * FH_WG;
+  uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x;
+#pragma unroll 8
+  for (; i < n2; i += stride) acc += p[i];
+  if (acc.x + acc.y == 1.2345e300) sink[0] = acc.x;   // never true; keeps the loads alive
+}

@@ -1,0 +1,124 @@
+// fh_device.h -- device-side building blocks shared by the FBS kernels (gfx950 / wave64 only).
+//
+// Conventions
+//   * 256-thread workgroups = 4 wavefronts of 64 lanes.
+//   * Elementwise solver arithmetic (forward step, prox, BB terms) is written with FMA contraction
+//     OFF so each operation rounds exactly like the NumPy expression it replaces
+//     (fasta/__init__.py:181, :242, :254); dot products and matvec accumulations use explicit fma().
+//   * Cross-workgroup hand-offs (partials -> last-arriving workgroup) follow the agent-scope
+//     release / acquire recipe of the CDNA4 guide (Guideline 16): every storing wave drains vmcnt,
+//     workgroup barrier, lane 0 release-fences and bumps an agent-scope counter; the workgroup whose
+//     add came last acquire-fences before any wave reads the partials.  All reductions are summed in
+//     index order, never arrival order, so results are bitwise repeatable run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d2 __attribute__((ext_vector_type(2)));   // one 16-byte global access
+
+#define FH_WG 256
+
+enum { PX_PLAIN = -1, PX_IDENTITY = 0, PX_SHRINK = 1, PX_NONNEG = 2, PX_LINF = 3, PX_L1BALL = 4, PX_TVBALL = 5, PX_BOX = 6 };
+
+struct ProxP {
+  int kind;
+  double thr;          // shrink: tau*mu (rounded on the host exactly like `t*self.mu`)
+  double lo, hi;       // box
+  const double* level; // LINF / L1BALL: device scalar holding the clipping level alpha
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the sum
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// sign(x) as NumPy defines it for finite x (np.sign): -1, 0 or +1
+__device__ __forceinline__ double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
+
+// proxg(x, t) for the scalar-separable kinds.  fasta/proximal.py:58-67 (shrink), :28-31 (linf tail),
+// :41 (l1 ball), examples/nn_least_squares.py:42 (non-negativity), examples/svm.py:71 (box).
+template <int KIND>
+__device__ __forceinline__ double prox_scalar(double x, const ProxP& px, double level) {
+#pragma clang fp contract(off)
+  if (KIND == PX_SHRINK) return sgn(x) * fmax(fabs(x) - px.thr, 0.0);
+  if (KIND == PX_NONNEG) return fmax(x, 0.0);
+  if (KIND == PX_BOX)    return fmin(fmax(x, px.lo), px.hi);
+  if (KIND == PX_LINF)   return level > 0.0 ? fmin(fabs(x), level) * sgn(x) : 0.0;
+  if (KIND == PX_L1BALL) return x - (level > 0.0 ? fmin(fabs(x), level) * sgn(x) : 0.0);
+  return x;
+}
+
+// forward (gradient) step x0 - tau*g0, two roundings as in fasta/__init__.py:181
+__device__ __forceinline__ double fwd_point(double x0, double g0, double tau) {
+#pragma clang fp contract(off)
+  double s = tau * g0;
+  return x0 - s;
+}
+
+// z + coef*(z - zprev), fasta/__init__.py:242-243 evaluation order
+__device__ __forceinline__ double extrapolate(double v, double vprev, double coef) {
+#pragma clang fp contract(off)
+  double d = v - vprev;
+  double s = coef * d;
+  return v + s;
+}
+
+// Dg = g1 + (xhat - x0)/tau, fasta/__init__.py:254
+__device__ __forceinline__ double bb_dgrad(double g1, double xhat, double x0, double tau) {
+#pragma clang fp contract(off)
+  double d = xhat - x0;
+  double q = d / tau;
+  return g1 + q;
+}
+
+__device__ __forceinline__ double sub_nofma(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+// Producer side of a "last workgroup finishes" hand-off; returns true in EVERY thread of the
+// workgroup whose arrival was the `total`-th.  `flag` is one LDS word owned by the caller.
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, volatile unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // keep the write-back ahead of the ticket
+    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned last = (t == total - 1u) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
+// 16-byte streaming load of A.  NT=1 marks it non-temporal (read-once stream; keeps x0/g0 in L2).
+template <int NT>
+__device__ __forceinline__ d2 load_stream(const d2* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// ---- synthetic generator (device twin of oracle/problems.py:synth_values) --------------------
+__host__ __device__ __forceinline__ uint64_t fh_mix(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ double fh_ihall(uint64_t key, uint64_t idx, double coef) {
+  uint64_t h1 = fh_mix(key + 2ull * idx), h2 = fh_mix(key + 2ull * idx + 1ull);
+  int64_t s = (int64_t)((h1 & 0xFFFF) + ((h1 >> 16) & 0xFFFF) + ((h1 >> 32) & 0xFFFF) + (h1 >> 48)
+                        + (h2 & 0xFFFF) + ((h2 >> 16) & 0xFFFF) + ((h2 >> 32) & 0xFFFF) + (h2 >> 48));
+  return (double)(s - 262140) * coef;
+}

@@ -1,0 +1,246 @@
+"""ctypes binding of libfasta_hip.so (C ABI: include/fasta_hip.h).
+
+This is the only module that talks to the GPU.  There is no CPU fallback anywhere in the package:
+if the shared library is missing or no MI355X is visible, `load_library()` / `HipContext()` raise.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfasta_hip.so")
+
+# enums mirrored from include/fasta_hip.h ---------------------------------------------------------
+PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PROX_BOX = range(7)
+(VEC_X0, VEC_G0, VEC_XHAT, VEC_XPROX, VEC_X1, VEC_G1, VEC_BEST, VEC_B, VEC_Z,
+ VEC_T0, VEC_T1, VEC_T2, VEC_T3) = range(13)
+(S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, S_GSUM, S_GMAX, S_RDOT, S_DXDG, S_DG2, S_FSQ_ADJ, S_XH2_ADJ,
+ S_GSUM_ADJ, S_GMAX_ADJ, S_ALPHA) = range(15)
+NSCALARS = 16
+K_FWD, K_ADJ, K_AUX, K_COMM = range(4)
+TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS = range(6)
+UNIQUE_ID_BYTES = 128
+
+_u64, _i32, _dbl = C.c_uint64, C.c_int, C.c_double
+_ctx = C.c_void_p
+_pd = C.POINTER(C.c_double)
+
+# every exported symbol with its signature; tests assert the .so exports exactly these ------------
+SIGNATURES = {
+    "fh_last_error": (C.c_char_p, []),
+    "fh_device_count": (_i32, [C.POINTER(_i32)]),
+    "fh_create": (_i32, [_i32, C.POINTER(_ctx)]),
+    "fh_destroy": (_i32, [_ctx]),
+    "fh_sync": (_i32, [_ctx]),
+    "fh_set_tuning": (_i32, [_ctx, _i32, C.c_longlong]),
+    "fh_set_matrix": (_i32, [_ctx, _pd, _u64, _u64, _u64]),
+    "fh_generate_matrix": (_i32, [_ctx, _u64, _u64, _u64, _u64, _dbl]),
+    "fh_get_matrix_rows": (_i32, [_ctx, _u64, _u64, _pd]),
+    "fh_set_stencil": (_i32, [_ctx, _u64, _u64]),
+    "fh_shape": (_i32, [_ctx, C.POINTER(_u64), C.POINTER(_u64)]),
+    "fh_set_loss_lsq": (_i32, [_ctx, _pd, _u64]),
+    "fh_set_prox": (_i32, [_ctx, _i32, _dbl, _dbl, _dbl]),
+    "fh_set_vector": (_i32, [_ctx, _i32, _pd, _u64]),
+    "fh_get_vector": (_i32, [_ctx, _i32, _pd, _u64]),
+    "fh_init": (_i32, [_ctx, _pd]),
+    "fh_gradient_at": (_i32, [_ctx, _i32, _i32]),
+    "fh_diff_norm": (_i32, [_ctx, _i32, _i32, _pd]),
+    "fh_fwd": (_i32, [_ctx, _dbl, _pd]),
+    "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
+    "fh_commit": (_i32, [_ctx, _i32]),
+    "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
+    "fh_comm_unique_id": (_i32, [C.c_void_p]),
+    "fh_comm_init": (_i32, [_ctx, _i32, _i32, C.c_void_p]),
+    "fh_comm_destroy": (_i32, [_ctx]),
+    "fh_timing_enable": (_i32, [_ctx, _i32]),
+    "fh_timing_get": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
+    "fh_timing_reset": (_i32, [_ctx]),
+    "fh_stream_read_ms": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    """Non-zero status from libfasta_hip.so (message = fh_last_error())."""
+
+
+def load_library(path=None):
+    """dlopen libfasta_hip.so and bind every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise HipError(f"{path} is missing -- build it with `python __graft_entry__.py` "
+                       "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(lib, status):
+    if status != 0:
+        raise HipError(f"[{status}] " + lib.fh_last_error().decode(errors="replace"))
+
+
+def _as_f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_pd)
+
+
+def device_count():
+    lib = load_library()
+    n = _i32(0)
+    _check(lib, lib.fh_device_count(C.byref(n)))
+    return n.value
+
+
+def comm_unique_id():
+    lib = load_library()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(lib, lib.fh_comm_unique_id(buf))
+    return buf.raw
+
+
+class HipContext:
+    """One device context (stream, device-resident A, vectors, workspace).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = _ctx()
+        _check(self.lib, self.lib.fh_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self._scal = np.zeros(NSCALARS)
+        self._scal_p = self._scal.ctypes.data_as(_pd)
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.fh_destroy(self._h)
+            self._h = _ctx()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        _check(self.lib, getattr(self.lib, name)(self._h, *args))
+
+    # ---- operator / problem data -----------------------------------------------------------------
+    def set_tuning(self, key, value):
+        self._call("fh_set_tuning", int(key), int(value))
+
+    def set_matrix(self, A):
+        assert A.ndim == 2
+        if A.dtype != np.float64 or not A.flags.c_contiguous:
+            A = np.ascontiguousarray(A, dtype=np.float64)
+        m, n = A.shape
+        self._call("fh_set_matrix", A.ctypes.data_as(_pd), m, n, n)
+
+    def generate_matrix(self, m, n, row0, seed, coef):
+        self._call("fh_generate_matrix", int(m), int(n), int(row0), int(seed), float(coef))
+
+    def get_matrix_rows(self, row0, nrows):
+        m, n = self.shape()
+        out = np.empty((nrows, n))
+        self._call("fh_get_matrix_rows", int(row0), int(nrows), out.ctypes.data_as(_pd))
+        return out
+
+    def set_stencil(self, H, W):
+        self._call("fh_set_stencil", int(H), int(W))
+
+    def shape(self):
+        m, n = _u64(0), _u64(0)
+        self._call("fh_shape", C.byref(m), C.byref(n))
+        return m.value, n.value
+
+    def set_loss_lsq(self, b):
+        b, p = _as_f64(np.ravel(b))
+        self._call("fh_set_loss_lsq", p, b.size)
+
+    def set_prox(self, kind, mu=0.0, lo=0.0, hi=0.0):
+        self._call("fh_set_prox", int(kind), float(mu), float(lo), float(hi))
+
+    def set_vector(self, which, v):
+        v, p = _as_f64(np.ravel(v))
+        self._call("fh_set_vector", int(which), p, v.size)
+
+    def get_vector(self, which, length):
+        out = np.empty(int(length))
+        self._call("fh_get_vector", int(which), out.ctypes.data_as(_pd), out.size)
+        return out
+
+    # ---- solver steps (scalars come back as a fresh copy of the FH_S_* block) ---------------------
+    def init(self):
+        self._call("fh_init", self._scal_p)
+        return self._scal.copy()
+
+    def gradient_at(self, src, dst):
+        self._call("fh_gradient_at", int(src), int(dst))
+
+    def diff_norm(self, a, b):
+        out = _dbl(0.0)
+        self._call("fh_diff_norm", int(a), int(b), C.byref(out))
+        return out.value
+
+    def fwd(self, tau):
+        self._call("fh_fwd", float(tau), self._scal_p)
+        return self._scal.copy()
+
+    def adj(self, tau, accel=False, coef=0.0):
+        self._call("fh_adj", float(tau), 1 if accel else 0, float(coef), self._scal_p)
+        return self._scal.copy()
+
+    def commit(self, save_best=False):
+        self._call("fh_commit", 1 if save_best else 0)
+
+    def apply(self, v, adjoint=False):
+        m, n = self.shape()
+        v, p = _as_f64(np.ravel(v))
+        assert v.size == (m if adjoint else n)
+        out = np.empty(n if adjoint else m)
+        self._call("fh_apply", 1 if adjoint else 0, p, out.ctypes.data_as(_pd))
+        return out
+
+    def sync(self):
+        self._call("fh_sync")
+
+    # ---- row sharding ---------------------------------------------------------------------------
+    def comm_init(self, nranks, rank, unique_id):
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        self._call("fh_comm_init", int(nranks), int(rank), buf)
+
+    def comm_destroy(self):
+        self._call("fh_comm_destroy")
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._call("fh_timing_enable", 1 if on else 0)
+
+    def timing_reset(self):
+        self._call("fh_timing_reset")
+
+    def timing_get(self, kernel_id):
+        ms, cnt = _dbl(0.0), _u64(0)
+        self._call("fh_timing_get", int(kernel_id), C.byref(ms), C.byref(cnt))
+        return ms.value, cnt.value
+
+    def stream_read_ms(self, reps=3):
+        ms, nbytes = _dbl(0.0), _u64(0)
+        self._call("fh_stream_read_ms", int(reps), C.byref(ms), C.byref(nbytes))
+        return ms.value, nbytes.value

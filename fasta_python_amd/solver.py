@@ -1,0 +1,284 @@
+"""`fasta()` -- the FBS driver, host control in Python, all vector work in fused HIP kernels.
+
+Drop-in for the reference call (fasta/__init__.py:38-53):
+
+    fasta(A, f, gradf, g, proxg, x0, **options)            # 6-positional core form
+    fasta(A, At, f, gradf, g, proxg, x0, **options)        # 7-positional form used by the examples
+
+with the reference's options, defaults and `Convergence` result.  Per iteration the host launches
+exactly two kernels -- K-fwd (`HipContext.fwd`) and K-adj (`HipContext.adj`) -- plus one extra K-fwd
+per backtrack, and reads back ~8 float64 scalars from each to take the reference's branch decisions
+(backtracking test :200, restart test :231, Barzilai-Borwein rule :253-270, stop rule :308).
+Iterates, gradients and residual vectors never leave HBM unless `record_iterates` / `func` ask.
+
+There is NO CPU fallback: operands that are not device-recognised raise TypeError (see `_recognise`).
+"""
+
+import warnings
+from time import time
+
+import numpy as np
+
+from . import hip, stopping
+from .linalg import DenseMatrixMap, GradDivMap, LinearMap, _DeviceMap
+from .losses import LeastSquares
+from .proximal import NoProx, ProxTag
+
+__all__ = ["fasta", "Convergence", "FBSolver", "EPSILON"]
+
+EPSILON = 1E-12      # fasta/__init__.py:32
+
+
+class Convergence:
+    """Result record with the reference's ten public attributes (fasta/__init__.py:323-351)."""
+
+    def __init__(self, residuals, norm_residuals, stepsizes, backtracks, times, iteration_count, solution,
+                 objectives=None, iterates=None, function_hist=None):
+        self.residuals = residuals
+        self.norm_residuals = norm_residuals
+        self.stepsizes = stepsizes
+        self.backtracks = backtracks
+        self.times = times
+        self.iteration_count = iteration_count
+        self.solution = solution
+        self.objectives = objectives
+        self.iterates = iterates
+        self.function_hist = function_hist
+
+
+def _tag_of(obj, cls):
+    """A tagged object passed directly, or as a bound method (`ls.f`, `reg.prox`, ...)."""
+    if isinstance(obj, cls):
+        return obj
+    owner = getattr(obj, "__self__", None)
+    return owner if isinstance(owner, cls) else None
+
+
+def _recognise(A, At, f, gradf, g, proxg, x0):
+    """Map the reference's seven operands onto device objects, or fail loudly."""
+    if isinstance(A, np.ndarray):
+        if A.ndim != 2:
+            raise AssertionError("matrix operator must be 2-D")            # linalg.py:40
+        if isinstance(At, np.ndarray) and At.shape != A.shape[::-1]:
+            raise AssertionError("At must have the transposed shape of A")
+        A = DenseMatrixMap(A)
+    if not isinstance(A, _DeviceMap):
+        raise TypeError(
+            "fasta(): operator A is not device-resident.  Pass a 2-D float64 ndarray, a "
+            "linalg.DenseMatrixMap / LinearMap.from_matrix(A), or a linalg.GradDivMap.  Arbitrary Python "
+            "callables cannot run inside the fused HIP kernels and this build has no CPU fallback.")
+    loss_f, loss_g = _tag_of(f, LeastSquares), _tag_of(gradf, LeastSquares)
+    if loss_f is None or loss_f is not loss_g:
+        raise TypeError("fasta(): f and gradf must be the `.f` / `.gradf` of one losses.LeastSquares(b) object")
+    if g is None and proxg is None:
+        prox = NoProx()                                                    # :88-90
+    else:
+        prox = _tag_of(proxg, ProxTag)
+        owner_g = _tag_of(g, ProxTag)
+        if prox is None or (owner_g is not None and owner_g is not prox):
+            raise TypeError("fasta(): g and proxg must be the `.g` / `.prox` of one proximal.* tag object "
+                            "(Shrink, NonNeg, LinfProx, L1Ball, Box, TVDualBall)")
+    if tuple(x0.shape) != A.Vshape:
+        raise AssertionError(f"x0 has shape {x0.shape}, operator expects {A.Vshape}")   # linalg.py:58
+    if loss_f.b.shape != A.Wshape:
+        raise AssertionError(f"b has shape {loss_f.b.shape}, operator produces {A.Wshape}")
+    return A, loss_f, prox
+
+
+def _half_sq(fsq):
+    """.5 * la.norm(r)**2 from the device's sum of squares (sparse_least_squares.py:41)."""
+    return .5 * np.sqrt(np.float64(fsq)) ** 2
+
+
+class FBSolver:
+    """The FBS loop as an object: `setup()` then `step()` until it returns True.  `fasta()` wraps it;
+    bench.py drives it directly so that warm-up and timed steps are the same code path."""
+
+    def __init__(self, A, loss, prox, x0, adaptive=True, accelerate=False, verbose=True, max_iters=1000,
+                 tolerance=1e-5, stop_rule=stopping.hybrid_residual, L=None, tau0=None, backtrack=True,
+                 stepsize_shrink=None, window=10, max_backtracks=20, restart=True, evaluate_objective=False,
+                 record_iterates=False, func=None):
+        self.A, self.loss, self.prox = A, loss, prox
+        self.ctx = A.ctx
+        self.x0 = np.asarray(x0, dtype=np.float64)
+        self.shape = self.x0.shape
+        self.n = int(self.x0.size)
+        if stepsize_shrink is None and backtrack:                       # :92-97
+            stepsize_shrink = 0.2 if adaptive else 0.5
+        self.adaptive, self.accelerate, self.verbose = adaptive, accelerate, verbose
+        self.max_iters, self.tolerance, self.stop_rule = max_iters, tolerance, stop_rule
+        self.L, self.tau0 = L, tau0
+        self.backtrack, self.stepsize_shrink = backtrack, stepsize_shrink
+        self.window, self.max_backtracks, self.restart = window, max_backtracks, restart
+        self.evaluate_objective, self.record_iterates, self.func = evaluate_objective, record_iterates, func
+
+    # ------------------------------------------------------------------------------------------
+    def setup(self):
+        c = self.ctx
+        c.set_loss_lsq(self.loss.b)
+        c.set_prox(self.prox.kind, self.prox.mu, self.prox.lo, self.prox.hi)
+        L, tau0 = self.L, self.tau0
+        if not L or not tau0:                                           # :100-113
+            p1 = np.random.randn(*self.shape)                           # same two global-RNG draws
+            p2 = np.random.randn(*self.shape)
+            c.set_vector(hip.VEC_T0, p1)
+            c.set_vector(hip.VEC_T1, p2)
+            c.gradient_at(hip.VEC_T0, hip.VEC_T2)
+            c.gradient_at(hip.VEC_T1, hip.VEC_T3)
+            L = np.float64(c.diff_norm(hip.VEC_T2, hip.VEC_T3)) / np.float64(c.diff_norm(hip.VEC_T0, hip.VEC_T1))
+            tau0 = (2 / L) / 10
+        if not tau0:                                                    # :115-116
+            tau0 = 1 / L
+        self.L, self.tau0 = L, tau0
+
+        if self.verbose:                                                # :118-120
+            print("Initializing FASTA...\n")
+            print("Iteration #\tResidual\tStepsize\tAccel. param\tBacktracks\tObjective")
+
+        K = self.max_iters
+        self.residuals = np.zeros(K)                                    # :123-127
+        self.norm_residuals = np.zeros(K)
+        self.stepsizes = np.zeros(K)
+        self.f_hist = np.zeros(K + 1)
+        self.times = np.zeros(K + 1)
+        self.total_backtracks = 0
+
+        c.set_vector(hip.VEC_X0, self.x0)
+        s = c.init()                                                    # :135-137
+        f1 = _half_sq(s[hip.S_FSQ])
+        self.f_hist[0] = f1
+        self.objectives = self.iterates = self.function_hist = None
+        if self.evaluate_objective:                                     # :141-143
+            self.objectives = np.zeros(K + 1)
+            self.objectives[0] = f1 + self.prox.g_from_sums(s[hip.S_GSUM], s[hip.S_GMAX])
+        if self.record_iterates:                                        # :145-147
+            self.iterates = np.zeros((K + 1,) + self.shape)
+            self.iterates[0] = self.x0
+        if self.func:                                                   # :149-151
+            self.function_hist = np.zeros(K + 1)
+            self.function_hist[0] = self.func(self.x0)
+        self.alpha1 = 1.0                                               # :157
+        self.max_residual = -np.inf                                     # :165-167
+        self.best_quality = np.inf
+        self.tau_next = tau0
+        self.i = 0
+        self.done = False
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def step(self):
+        """One FBS iteration (fasta/__init__.py:171-312).  Returns True when the stop rule fires."""
+        c, i = self.ctx, self.i
+        self.times[i] = time()                                          # :173
+        tau = self.tau_next                                             # :178
+
+        s = c.fwd(tau)                                                  # :181-188  (K-fwd)
+        f1 = _half_sq(s[hip.S_FSQ])
+        bt = 0
+        if self.backtrack:                                              # :195-217
+            M = np.max(self.f_hist[max(i - self.window + 1, 0):(i + 1)])
+            while (f1 - (M + s[hip.S_DXG0] + np.sqrt(s[hip.S_DX2]) ** 2 / (2 * tau)) > EPSILON
+                   and bt < self.max_backtracks):
+                tau *= self.stepsize_shrink
+                s = c.fwd(tau)                                          # :207-213  (K-fwd again)
+                f1 = _half_sq(s[hip.S_FSQ])
+                bt += 1
+            self.total_backtracks += bt
+
+        alpha0, coef = 0.0, 0.0
+        if self.accelerate:                                             # :220-238
+            alpha0 = self.alpha1
+            if self.restart and s[hip.S_RDOT] > 1E-30:
+                alpha0 = 1.0
+                if self.verbose:
+                    print("Restarted acceleration.")
+            self.alpha1 = (1 + np.sqrt(1 + 4 * alpha0 ** 2)) / 2
+            coef = (alpha0 - 1) / self.alpha1
+
+        a = c.adj(tau, self.accelerate, coef)                           # :242-248  (K-adj)
+        if self.accelerate:
+            f1 = _half_sq(a[hip.S_FSQ_ADJ])                             # :245
+            xh2, gsum, gmax = a[hip.S_XH2_ADJ], a[hip.S_GSUM_ADJ], a[hip.S_GMAX_ADJ]
+        else:
+            xh2, gsum, gmax = s[hip.S_XH2], s[hip.S_GSUM], s[hip.S_GMAX]
+
+        tau_next = tau                                                  # :249
+        dx_norm = np.sqrt(s[hip.S_DX2])
+        if self.adaptive:                                               # :253-270
+            dot = a[hip.S_DXDG]
+            tau_s = dx_norm ** 2 / dot
+            tau_m = max(dot / np.sqrt(a[hip.S_DG2]) ** 2, 0)
+            tau_next = tau_m if 2 * tau_m > tau_s else tau_s - .5 * tau_m
+            if tau_next <= 0 or np.isinf(tau_next) or np.isnan(tau_next):
+                tau_next = tau * 1.5
+        self.tau_next = tau_next
+
+        self.residuals[i] = dx_norm / tau                               # :272
+        normalizer = max(np.sqrt(s[hip.S_G02]), np.sqrt(xh2) / tau) + EPSILON      # :274
+        self.stepsizes[i] = tau
+        self.norm_residuals[i] = self.residuals[i] / normalizer
+        self.f_hist[i + 1] = f1
+        self.max_residual = max(self.max_residual, self.residuals[i])   # :281
+
+        if self.evaluate_objective:                                     # :284-289
+            self.objectives[i + 1] = f1 + self.prox.g_from_sums(gsum, gmax)
+            quality = self.objectives[i + 1]
+        else:
+            quality = self.residuals[i]
+        better = bool(quality < self.best_quality)                      # :298-300
+        if better:
+            self.best_quality = quality
+        c.commit(save_best=better)                                      # x0 <- x1, g0 <- g1 (:176-177)
+
+        if self.record_iterates or self.func:                           # :291-296 (D2H of x1, off the fast path)
+            x1 = c.get_vector(hip.VEC_X0, self.n).reshape(self.shape)
+            if self.record_iterates:
+                self.iterates[i + 1, ...] = x1
+            if self.func:
+                self.function_hist[i + 1] = self.func(x1)
+
+        if self.verbose:                                                # :302-306
+            print("[{:<6}]\t{:e}\t{:e}\t{:e}\t{:6}\t{:e}".format(
+                i, self.residuals[i], self.stepsizes[i], alpha0 if self.accelerate else 0.0,
+                bt if self.backtrack else 0, self.objectives[i] if self.evaluate_objective else 0))
+
+        self.i = i + 1                                                  # :308-312
+        self.done = bool(self.stop_rule(i, self.residuals[i], self.norm_residuals[i], self.max_residual,
+                                        self.tolerance)) or self.i >= self.max_iters
+        return self.done
+
+    def run(self):
+        with warnings.catch_warnings():
+            # the reference relies on float64 inf/nan semantics (e.g. 0/0 in the BB rule once converged)
+            warnings.simplefilter("ignore", RuntimeWarning)
+            with np.errstate(all="ignore"):
+                while self.i < self.max_iters:
+                    if self.step():
+                        break
+        return self.result()
+
+    def result(self):
+        self.times[self.i] = time()                                     # :315
+        solution = self.ctx.get_vector(hip.VEC_BEST, self.n).reshape(self.shape)
+        return Convergence(self.residuals, self.norm_residuals, self.stepsizes, self.total_backtracks, self.times,
+                           self.i, solution, self.objectives, self.iterates, self.function_hist)
+
+
+def fasta(A, *operands, **options):
+    """Run FASTA on the MI355X.  Same positional forms, keyword options and defaults as the reference
+    (fasta/__init__.py:38-53); returns `Convergence`."""
+    if len(operands) == 6:
+        At, f, gradf, g, proxg, x0 = operands
+    elif len(operands) == 5:
+        At = None
+        f, gradf, g, proxg, x0 = operands
+    else:
+        raise TypeError("fasta() takes (A, f, gradf, g, proxg, x0) or (A, At, f, gradf, g, proxg, x0)")
+    x0 = np.asarray(x0, dtype=np.float64)
+    owns = isinstance(A, np.ndarray)
+    A, loss, prox = _recognise(A, At, f, gradf, g, proxg, x0)
+    try:
+        return FBSolver(A, loss, prox, x0, **options).setup().run()
+    finally:
+        if owns:
+            A.close()

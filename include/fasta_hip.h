@@ -1,0 +1,156 @@
+/* fasta_hip.h -- C ABI of libfasta_hip.so: the MI355X (gfx950) forward-backward-splitting hot path.
+ *
+ * The reference (phasepack/fasta-python) is pure Python and has no FFI; its plugin boundary for this
+ * path is the Python call fasta.fasta(A[, At], f, gradf, g, proxg, x0, ...) (fasta/__init__.py:38-53).
+ * This header is the boundary a binding for that call sits on: plain pointers and sizes, no torch
+ * types.  Each entry point cites the reference arithmetic it replaces (paths relative to the
+ * reference tree).  The ctypes binding that consumes it is fasta_python_amd/hip.py; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a non-zero code (hipError_t / ncclResult_t
+ *     value, or FH_E_*); fh_last_error() then describes it (thread-local string).
+ *   - one fh_ctx per device per process; a context is NOT thread-safe; calls are synchronous from
+ *     the caller's view (fh_fwd / fh_adj return once their scalars are on the host).
+ *   - the library copies on every set_* and never keeps a host pointer past the call; it owns all
+ *     device memory behind fh_ctx until fh_destroy.
+ *   - all arithmetic is IEEE float64 (the reference is float64 throughout).
+ */
+#ifndef FASTA_HIP_H
+#define FASTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fh_ctx fh_ctx;
+
+#define FH_E_ARG      10001   /* bad argument / shape mismatch                      */
+#define FH_E_STATE    10002   /* call out of order (e.g. fh_fwd before fh_set_*)     */
+#define FH_E_RCCL     10003   /* librccl could not be loaded / symbol missing        */
+
+/* prox operators g(x) <-> proxg(x, t)                                                   */
+enum fh_prox_kind {
+  FH_PROX_IDENTITY = 0,  /* g = None branch, fasta/__init__.py:88-90                     */
+  FH_PROX_SHRINK   = 1,  /* proximal.shrink(x, t*mu), fasta/proximal.py:58-67            */
+  FH_PROX_NONNEG   = 2,  /* np.maximum(x, 0), examples/nn_least_squares.py:42            */
+  FH_PROX_LINF     = 3,  /* proximal.project_Linf_ball(x, t*mu), fasta/proximal.py:12-31 */
+  FH_PROX_L1BALL   = 4,  /* proximal.project_L1_ball(x, mu), fasta/proximal.py:34-41     */
+  FH_PROX_TVBALL   = 5,  /* per-pixel 2-vector / max(norm,1), examples/tv_denoising.py:89-96 */
+  FH_PROX_BOX      = 6   /* clip to [lo, hi], examples/svm.py:71                         */
+};
+
+/* device vectors addressable through fh_set_vector / fh_get_vector                      */
+enum fh_vec {
+  FH_VEC_X0 = 0,    /* current iterate x0 (n)            fasta/__init__.py:176            */
+  FH_VEC_G0 = 1,    /* gradient at x0: A^H grad f(A x0)  :177                             */
+  FH_VEC_XHAT = 2,  /* forward point x0 - tau*g0         :181                             */
+  FH_VEC_XPROX = 3, /* prox output (pre-acceleration x1) :184                             */
+  FH_VEC_X1 = 4,    /* next iterate (post-acceleration)  :242                             */
+  FH_VEC_G1 = 5,    /* next gradient                     :248                             */
+  FH_VEC_BEST = 6,  /* best-quality iterate so far       :298-300                         */
+  FH_VEC_B = 7,     /* least-squares target b (m)        examples/sparse_least_squares.py:41 */
+  FH_VEC_Z = 8,     /* z1 = A xprox (m)                  :187                             */
+  FH_VEC_T0 = 9, FH_VEC_T1 = 10, FH_VEC_T2 = 11, FH_VEC_T3 = 12   /* n-length scratch     */
+};
+
+/* layout of the scalar block written by fh_init / fh_fwd / fh_adj (FH_NSCALARS doubles)  */
+enum fh_scalar {
+  FH_S_FSQ = 0,     /* ||z1 - b||^2 ; f1 = .5*sqrt(.)**2      :188                        */
+  FH_S_DXG0 = 1,    /* <Dx, g0>                                 :200                        */
+  FH_S_DX2 = 2,     /* ||Dx||^2 , Dx = xprox - x0               :200, :258, :272            */
+  FH_S_XH2 = 3,     /* ||xprox - xhat||^2 (normaliser, no accel):274                        */
+  FH_S_G02 = 4,     /* ||g0||^2                                 :274                        */
+  FH_S_GSUM = 5,    /* sum |xprox_i|   (g for shrink = mu*this) examples/sparse_least_squares.py:43 */
+  FH_S_GMAX = 6,    /* max |xprox_i|   (g for linf  = mu*this)  examples/democratic_representation.py:41 */
+  FH_S_RDOT = 7,    /* (x0 - xprox).(xprox - xacc0)  restart    :231                        */
+  FH_S_DXDG = 8,    /* <Dx, Dg>, Dg = g1 + (xhat - x0)/tau      :254-255                    */
+  FH_S_DG2 = 9,     /* ||Dg||^2                                 :260                        */
+  FH_S_FSQ_ADJ = 10,/* ||z1' - b||^2 at the extrapolated z1'    :243-245                    */
+  FH_S_XH2_ADJ = 11,/* ||x1 - xhat||^2 with extrapolated x1     :274                        */
+  FH_S_GSUM_ADJ = 12, FH_S_GMAX_ADJ = 13,   /* g terms at the extrapolated x1 :285           */
+  FH_S_ALPHA = 14,  /* threshold level used by LINF / L1BALL prox (diagnostic)              */
+  FH_NSCALARS = 16
+};
+
+enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_NKERNELS = 4 };
+
+enum fh_tuning_key {
+  FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8 or 16                */
+  FH_TUNE_FWD_GRID_CAP = 1,  /* max workgroups of K-fwd (0 = one row group per workgroup)   */
+  FH_TUNE_ADJ_SLAB_ROWS = 2, /* rows per K-adj slab (multiple of 8; 0 = auto)               */
+  FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4           */
+  FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
+  FH_TUNE_NT_LOADS = 5       /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
+};
+
+/* ---- library / context -------------------------------------------------------------- */
+const char* fh_last_error(void);
+int fh_device_count(int* count);
+int fh_create(int device, fh_ctx** out);
+int fh_destroy(fh_ctx* ctx);
+int fh_sync(fh_ctx* ctx);
+int fh_set_tuning(fh_ctx* ctx, int key, long long value);
+
+/* ---- operator A (replaces LinearMap.from_matrix closures `A @ x`, `A.T @ x`, fasta/linalg.py:37-41) */
+/* dense row-major host matrix, m rows, n columns, leading dimension ld_host (doubles).          */
+int fh_set_matrix(fh_ctx* ctx, const double* A, uint64_t m, uint64_t n, uint64_t ld_host);
+/* synthetic rows [row0, row0+m) of a (.., n) matrix: element (i,j) = ihall(seed, (row0+i)*n + j) * coef
+ * (device twin of oracle/problems.py:synth_values).                                            */
+int fh_generate_matrix(fh_ctx* ctx, uint64_t m, uint64_t n, uint64_t row0, uint64_t seed, double coef);
+int fh_get_matrix_rows(fh_ctx* ctx, uint64_t row0, uint64_t nrows, double* out /* nrows*n */);
+/* periodic difference stencil pair: A = div: (H,W,2)->(H,W), A^H = grad (examples/tv_denoising.py:26-63) */
+int fh_set_stencil(fh_ctx* ctx, uint64_t H, uint64_t W);
+int fh_shape(fh_ctx* ctx, uint64_t* m, uint64_t* n);
+
+/* ---- smooth term f(z) = .5||z - b||^2, grad f(z) = z - b (examples/sparse_least_squares.py:41-42) */
+int fh_set_loss_lsq(fh_ctx* ctx, const double* b, uint64_t len);
+/* ---- prox term (kinds above); mu as in the closures, lo/hi for FH_PROX_BOX only              */
+int fh_set_prox(fh_ctx* ctx, int kind, double mu, double lo, double hi);
+
+int fh_set_vector(fh_ctx* ctx, int which, const double* host, uint64_t len);
+int fh_get_vector(fh_ctx* ctx, int which, double* host, uint64_t len);
+
+/* ---- solver steps -------------------------------------------------------------------- */
+/* fasta/__init__.py:132-137: z1 = A x0, f1 = f(z1), g0 = A^H grad f(z1); arms the acceleration
+ * state (x_accel1 = x0, z_accel1 = z1, :154-157).  scalars: FH_S_FSQ, FH_S_GSUM, FH_S_GMAX.       */
+int fh_init(fh_ctx* ctx, double* scalars);
+/* dst = A^H grad f(A src) for n-length device vectors (Lipschitz probes, fasta/__init__.py:106-107) */
+int fh_gradient_at(fh_ctx* ctx, int src_vec, int dst_vec);
+/* ||a - b||_2 of two n-length device vectors (fasta/__init__.py:110)                             */
+int fh_diff_norm(fh_ctx* ctx, int vec_a, int vec_b, double* out);
+/* K-fwd, one launch: xhat = x0 - tau*g0; xprox = prox(xhat, tau); z1 = A xprox; reductions
+ * FH_S_FSQ..FH_S_RDOT (fasta/__init__.py:181-188, 200, 231, 272-274).  May be called repeatedly
+ * with a smaller tau (backtracking, :204-213).                                                   */
+int fh_fwd(fh_ctx* ctx, double tau, double* scalars);
+/* K-adj, one launch (+ one RCCL all-reduce when row-sharded): z1' = z1 + coef*(z1 - z_accel0),
+ * x1 = xprox + coef*(xprox - x_accel0) (coef = 0 and accel = 0 without acceleration, :242-243);
+ * g1 = A^H (z1' - b) (:248); reductions FH_S_DXDG..FH_S_GMAX_ADJ (:254-260, 274, 285).          */
+int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
+/* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
+ * copies x1 into FH_VEC_BEST (:298-300).                                                         */
+int fh_commit(fh_ctx* ctx, int save_best);
+/* plain operator application on host vectors (tests, synthetic b): adjoint=0: out(m) = A in(n);
+ * adjoint=1: out(n) = A^H in(m).                                                                 */
+int fh_apply(fh_ctx* ctx, int adjoint, const double* in, double* out);
+
+/* ---- row sharding across GPUs: one process per GPU, RCCL communicator by rank ----------------- */
+/* writes an ncclUniqueId (128 bytes) -- rank 0 calls it and ships the bytes to the other ranks     */
+int fh_comm_unique_id(void* id128);
+int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
+int fh_comm_destroy(fh_ctx* ctx);
+
+/* ---- measurement: HIP-event timing of each launch on the context's stream --------------------- */
+int fh_timing_enable(fh_ctx* ctx, int on);
+int fh_timing_get(fh_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
+int fh_timing_reset(fh_ctx* ctx);
+/* streaming-read ceiling: reads the device copy of A once with 16-byte loads, returns ms       */
+int fh_stream_read_ms(fh_ctx* ctx, int reps, double* ms_per_pass, uint64_t* bytes_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTA_HIP_H */

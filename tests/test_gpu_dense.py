@@ -1,0 +1,190 @@
+"""GPU parity tests for the dense operator path, all through the C ABI (libfasta_hip.so).
+
+Tolerances (north-star: iterate-for-iterate rtol 1e-5): matvecs rtol 1e-12 (float64, different
+summation order than OpenBLAS); histories rtol 1e-6; iterates/solution rtol 1e-5 (+1e-9 abs).
+"""
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from fasta_python_amd import hip
+from oracle import fasta_np as fo
+from oracle import problems as pr
+from tests import gpu_util as G
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 1), (1, 7), (3, 5), (16, 16), (17, 33), (64, 128), (128, 64), (200, 1000), (513, 1025), (1024, 96)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_apply_matches_numpy(m, n):
+    rng = np.random.RandomState(m * 1000 + n)
+    A = rng.randn(m, n)
+    x, y = rng.randn(n), rng.randn(m)
+    op = fa.DenseMatrixMap(A)
+    try:
+        np.testing.assert_allclose(op(x), A @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.H(y), A.T @ y, rtol=1e-12, atol=1e-12)
+        with pytest.raises(AssertionError):
+            op(np.zeros(n + 1))                                     # fasta/linalg.py:58
+    finally:
+        op.close()
+
+
+@pytest.mark.parametrize("cpt,rows,nt", [(1, 4, 1), (2, 8, 0), (4, 16, 1)])
+def test_apply_all_kernel_variants(cpt, rows, nt):
+    rng = np.random.RandomState(7)
+    A = rng.randn(300, 1100)
+    x, y = rng.randn(1100), rng.randn(300)
+    op = fa.DenseMatrixMap(A, tuning={hip.TUNE_ADJ_CPT: cpt, hip.TUNE_FWD_ROWS: rows, hip.TUNE_NT_LOADS: nt,
+                                      hip.TUNE_LD_PAD: 32, hip.TUNE_ADJ_SLAB_ROWS: 40, hip.TUNE_FWD_GRID_CAP: 7})
+    try:
+        np.testing.assert_allclose(op(x), A @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.H(y), A.T @ y, rtol=1e-12, atol=1e-12)
+    finally:
+        op.close()
+
+
+def test_synthetic_generator_is_bit_identical_to_host_twin():
+    m, n, seed, scale = 37, 101, 5, 0.125
+    op = fa.DenseMatrixMap.synthetic(m, n, seed, scale, row0=11)
+    try:
+        got = op.host_rows(0, m)
+        want = pr.synth_matrix(m, n, seed, scale, row0=11)
+        assert np.array_equal(got, want)
+        assert abs(want.std() - scale) < 0.05 * scale
+    finally:
+        op.close()
+
+
+def test_single_step_scalars_match_numpy():
+    """One K-fwd + K-adj against the NumPy expressions of fasta/__init__.py:181-188, 200, 254-274."""
+    rng = np.random.RandomState(3)
+    m, n, mu, tau = 96, 200, 0.05, 0.3
+    A = rng.randn(m, n) / 10
+    b = rng.randn(m)
+    x0 = rng.randn(n) * 0.1
+    op = fa.DenseMatrixMap(A)
+    c = op.ctx
+    try:
+        c.set_loss_lsq(b)
+        c.set_prox(hip.PROX_SHRINK, mu)
+        c.set_vector(hip.VEC_X0, x0)
+        s0 = c.init()
+        g0 = A.T @ (A @ x0 - b)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G0, n), g0, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(s0[hip.S_FSQ], np.sum((A @ x0 - b) ** 2), rtol=1e-12)
+        s = c.fwd(tau)
+        xhat = x0 - tau * g0
+        xp = fo.shrink(xhat, tau * mu)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_XHAT, n), xhat, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_XPROX, n), xp, rtol=1e-12, atol=1e-14)
+        dx = xp - x0
+        z = A @ xp
+        want = {hip.S_FSQ: np.sum((z - b) ** 2), hip.S_DXG0: dx @ g0, hip.S_DX2: dx @ dx,
+                hip.S_XH2: np.sum((xp - xhat) ** 2), hip.S_G02: g0 @ g0, hip.S_GSUM: np.abs(xp).sum(),
+                hip.S_GMAX: np.abs(xp).max()}
+        for k, v in want.items():
+            np.testing.assert_allclose(s[k], v, rtol=1e-11, atol=1e-13, err_msg=str(k))
+        a = c.adj(tau)
+        g1 = A.T @ (z - b)
+        dg = g1 + (xhat - x0) / tau
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), g1, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(a[hip.S_DXDG], dx @ dg, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(a[hip.S_DG2], dg @ dg, rtol=1e-10, atol=1e-13)
+        # accelerated variant of the same step: extrapolated x1 / z1 (fasta/__init__.py:242-245)
+        coef = 0.37
+        a2 = c.adj(tau, accel=True, coef=coef)
+        x1 = xp + coef * (xp - x0)                 # x_accel0 = x0 after init
+        z1 = z + coef * (z - A @ x0)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_X1, n), x1, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(a2[hip.S_FSQ_ADJ], np.sum((z1 - b) ** 2), rtol=1e-11)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), A.T @ (z1 - b), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(a2[hip.S_XH2_ADJ], np.sum((x1 - xhat) ** 2), rtol=1e-11)
+    finally:
+        op.close()
+
+
+DENSE_FULL = [n for n in H.golden_cases()
+              if n.split("_")[0] in ("sparse", "nnls", "c1") and "unnormalised" not in n and "under" not in n
+              and "window3" not in n]
+DENSE_PREFIX = {"sparse_ls_unnormalised_backtracks": 25, "nnls_under_first40": 25, "sparse_ls_opt_window3_shrink": 25}
+
+
+@pytest.mark.parametrize("name", DENSE_FULL)
+def test_golden_parity_full_solve(name):
+    """HIP solve vs the REFERENCE's recorded run: same iteration count, same backtracks, histories and
+    iterates within tolerance on every iteration."""
+    meta, z = H.load_case(name)
+    data = H.case_data(meta, z)
+    c = G.run_hip(meta["kind"], data, meta["options"], meta["solver_seed"], g_none=meta["options"].get("g_none", False))
+    assert c.iteration_count == int(z["iteration_count"])
+    assert c.backtracks == int(z["backtracks"])
+    get = lambda f: z[f] if f in z.files else None
+    G.compare_histories(c, get, c.iteration_count, rtol=1e-6, atol=1e-14)
+    np.testing.assert_allclose(c.solution, z["solution"], rtol=1e-5, atol=1e-9)
+    if "iterates" in z.files:
+        k = c.iteration_count + 1
+        np.testing.assert_allclose(c.iterates[:k], z["iterates"][:k], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(c.function_hist[:k], z["function_hist"][:k], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,k", sorted(DENSE_PREFIX.items()))
+def test_golden_parity_prefix_of_sensitive_runs(name, k):
+    """Backtracking-heavy / non-convergent runs amplify rounding: pin the first k
+    iterations, including where the backtracks fall."""
+    meta, z = H.load_case(name)
+    data = H.case_data(meta, z)
+    opts = dict(meta["options"], max_iters=k, tolerance=0.0)
+    c = G.run_hip(meta["kind"], data, opts, meta["solver_seed"])
+    np.testing.assert_allclose(c.stepsizes[:k], z["stepsizes"][:k], rtol=1e-6)
+    np.testing.assert_allclose(c.residuals[:k], z["residuals"][:k], rtol=1e-6)
+    np.testing.assert_allclose(c.norm_residuals[:k], z["norm_residuals"][:k], rtol=1e-6)
+
+
+def test_runs_are_bitwise_repeatable():
+    meta, z = H.load_case("sparse_ls_64x128_adaptive")
+    data = H.case_data(meta, z)
+    a = G.run_hip(meta["kind"], data, meta["options"], meta["solver_seed"])
+    b = G.run_hip(meta["kind"], data, meta["options"], meta["solver_seed"])
+    for f in ("residuals", "norm_residuals", "stepsizes", "objectives", "solution"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_unrecognised_operands_fail_loudly():
+    A = np.eye(4)
+    ls, reg = fa.LeastSquares(np.zeros(4)), fa.Shrink(0.1)
+    with pytest.raises(TypeError):
+        fa.fasta(lambda x: x, lambda x: x, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(4))
+    with pytest.raises(TypeError):
+        fa.fasta(A, A.T, lambda z: 0.0, lambda z: z, reg.g, reg.prox, np.zeros(4))
+    with pytest.raises(TypeError):
+        fa.fasta(A, A.T, ls.f, ls.gradf, lambda x: 0, lambda x, t: x, np.zeros(4))
+    with pytest.raises(AssertionError):
+        fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5))
+
+
+@pytest.mark.parametrize("m,n", [(4096, 4096), (16384, 2048)])
+def test_mid_size_matches_oracle_loop(m, n):
+    """Synthetic LASSO: HIP loop vs oracle loop on the same (device-generated) matrix, every iteration."""
+    scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap.synthetic(m, n, 0, scale)
+    try:
+        A = op.host_rows(0, m)
+        x_true = pr.synth_sparse_signal(n, 1)
+        b = A @ x_true + 0.01 * np.random.RandomState(2).randn(m)
+        ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+        opts = dict(tolerance=1e-6, max_iters=60, evaluate_objective=True, record_iterates=True)
+        np.random.seed(3)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, **opts)
+        P = pr.sparse_least_squares_from(A, b, 0.02)
+        np.random.seed(3)
+        want = fo.fasta(*P.args7(), **opts)
+        assert got.iteration_count == want.iteration_count and got.backtracks == want.backtracks
+        k = got.iteration_count
+        G.compare_histories(got, lambda f: getattr(want, f), k, rtol=1e-6, atol=1e-14)
+        np.testing.assert_allclose(got.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
+    finally:
+        op.close()
