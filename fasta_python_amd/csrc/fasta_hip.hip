@@ -127,9 +127,9 @@ struct fh_ctx {
   double* hscal = nullptr;           // pinned host mirror
   // tuning
   int fwd_rows = 8;
-  long long fwd_cap = 0;
-  int adj_slab = 0;
-  int adj_cpt = 2;
+  long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
+  int adj_slab = 0;          // 0 = auto
+  int adj_cpt = 0;           // 0 = auto
   int ld_pad = 0;
   int nt_loads = 1;
   // timing
@@ -293,7 +293,7 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > ADJ_MAX_SLAB || value % 8) return fail(FH_E_ARG, "ADJ_SLAB_ROWS must be a multiple of 8 in [0,%d]", ADJ_MAX_SLAB);
       c->adj_slab = (int)value; return 0;
     case FH_TUNE_ADJ_CPT:
-      if (value != 1 && value != 2 && value != 4) return fail(FH_E_ARG, "ADJ_CPT must be 1, 2 or 4");
+      if (value != 0 && value != 1 && value != 2 && value != 4) return fail(FH_E_ARG, "ADJ_CPT must be 0 (auto), 1, 2 or 4");
       c->adj_cpt = (int)value; return 0;
     case FH_TUNE_LD_PAD:
       if (value < 0 || value % 16) return fail(FH_E_ARG, "LD_PAD must be a non-negative multiple of 16");
@@ -484,7 +484,9 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   p.px = make_prox(c, tau);
   const int kind = mode == 0 ? c->prox_kind : (int)PX_PLAIN;
   unsigned grid = std::max(p.nrg, mode == 0 ? p.nchunks : 1u);
-  if (c->fwd_cap > 0) grid = (unsigned)std::min<long long>(grid, c->fwd_cap);
+  // measured on MI355X at 65536^2 (profiles/r01_tune_dense.txt): ~4 persistent workgroups per CU beat one
+  // workgroup per row group by 5-12 %
+  grid = (unsigned)std::min<long long>(grid, c->fwd_cap > 0 ? c->fwd_cap : 1024);
   const size_t need = ((size_t)p.nchunks * 8 + grid) * sizeof(double);
   FH_TRY(ensure_ws(c, need));
   p.red_n = c->ws; p.red_m = c->ws + (size_t)p.nchunks * 8;
@@ -515,13 +517,16 @@ struct AdjIO {
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
-  const int CPT = c->adj_cpt;
+  // auto rules from the MI355X sweep (profiles/r01_tune_dense.txt): wide column chunks (4 x 16 B per lane) and
+  // ~1024 workgroups of up to 2048 rows each were fastest at 65536^2 (6.9 TB/s); narrower chunks for small n
+  int CPT = c->adj_cpt;
+  if (CPT == 0) CPT = p.ld2 >= 4096 ? 4 : (p.ld2 >= 1024 ? 2 : 1);
   p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
   uint32_t slab = (uint32_t)c->adj_slab;
-  if (slab == 0) {   // auto: aim for ~4096 workgroups, 32..1024 rows per slab
-    const uint64_t target_slabs = std::max<uint64_t>(1, 4096 / p.ncc);
+  if (slab == 0) {
+    const uint64_t target_slabs = std::max<uint64_t>(1, 1024 / p.ncc);
     uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
-    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, 32), 1024);
+    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, 32), ADJ_MAX_SLAB);
   }
   p.slab_rows = slab;
   p.nslab = (uint32_t)((c->mp + slab - 1) / slab);

@@ -80,9 +80,9 @@ enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_
 
 enum fh_tuning_key {
   FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8 or 16                */
-  FH_TUNE_FWD_GRID_CAP = 1,  /* max workgroups of K-fwd (0 = one row group per workgroup)   */
+  FH_TUNE_FWD_GRID_CAP = 1,  /* max workgroups of K-fwd (0 = auto: 1024, grid-stride over row groups) */
   FH_TUNE_ADJ_SLAB_ROWS = 2, /* rows per K-adj slab (multiple of 8; 0 = auto)               */
-  FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4           */
+  FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */
   FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
   FH_TUNE_NT_LOADS = 5       /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
 };

@@ -188,3 +188,24 @@ def test_mid_size_matches_oracle_loop(m, n):
         np.testing.assert_allclose(got.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("accelerate", [False, True])
+def test_row_sharded_code_path_with_one_rank_communicator(accelerate):
+    """The sharded adjoint (partial g1 -> RCCL all-reduce -> separate n-side epilogue) on a 1-rank
+    communicator must reproduce the fused single-GPU launch (the 8-GPU run is the driver's)."""
+    meta, z = H.load_case("sparse_ls_64x128_adaptive")
+    data = H.case_data(meta, z)
+    opts = dict(tolerance=1e-5, evaluate_objective=True, adaptive=not accelerate, accelerate=accelerate)
+    ref = G.run_hip("sparse_ls", data, opts, 5)
+    A, loss, reg, x0 = G.hip_operands("sparse_ls", data)
+    try:
+        A.ctx.comm_init(1, 0, hip.comm_unique_id())
+        np.random.seed(5)
+        got = fa.fasta(A, loss.f, loss.gradf, reg.g, reg.prox, x0, verbose=False, **opts)
+    finally:
+        A.close()
+    assert got.iteration_count == ref.iteration_count and got.backtracks == ref.backtracks
+    k = got.iteration_count
+    G.compare_histories(got, lambda f: getattr(ref, f), k, rtol=1e-12)
+    np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
