@@ -13,6 +13,7 @@
 #include "../../include/fasta_hip.h"
 #include "fh_dense.h"
 #include "fh_tv.h"
+#include "fh_prox.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -357,7 +358,7 @@ extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, doub
 
 extern "C" int fh_set_stencil(fh_ctx* c, uint64_t H, uint64_t W) {
   if (!c) return fail(FH_E_ARG, "null context");
-  if (H < 1 || W < 1 || (W % 2) != 0) return fail(FH_E_ARG, "stencil needs H>=1 and even W>=2 (got %llu x %llu)", (unsigned long long)H, (unsigned long long)W);
+  if (H < 1 || W < 1) return fail(FH_E_ARG, "stencil needs H>=1 and W>=1 (got %llu x %llu)", (unsigned long long)H, (unsigned long long)W);
   if (H * W >= (1ull << 31)) return fail(FH_E_ARG, "image too large");
   FH_TRY(use_device(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -587,16 +588,61 @@ static int launch_gterms(fh_ctx* c, const double* x) {
   return 0;
 }
 
+// clipping level alpha for FH_PROX_LINF (radius tau*mu) / FH_PROX_L1BALL (radius mu) -> dscal[FH_NSCALARS]
 static int launch_level_search(fh_ctx* c, double tau) {
-  (void)tau;
-  return fail(FH_E_STATE, "LINF / L1BALL prox: level search not built yet");
+  if (c->op != OP_DENSE) return fail(FH_E_STATE, "LINF / L1BALL prox need the dense operator");
+  const double radius = c->prox_kind == FH_PROX_L1BALL ? c->mu : tau * c->mu;
+  const double* x0 = c->X[c->xc];
+  const double* g0 = c->G[c->gc];
+  double* out = c->dscal + FH_NSCALARS;
+  const uint32_t n = (uint32_t)c->n;
+  t_begin(c, FH_K_AUX);
+  if (n <= 1u * LVL_WG) k_level_search<1><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else if (n <= 4u * LVL_WG) k_level_search<4><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else if (n <= 16u * LVL_WG) k_level_search<16><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else if (n <= 64u * LVL_WG) k_level_search<64><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else k_level_search<0><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  t_end(c, FH_K_AUX);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
-static int launch_fwd_tv(fh_ctx* c, int, double, const double*, const double*, const double*, double*, double*, double*, int) {
-  (void)c; return fail(FH_E_STATE, "stencil operator kernels not built yet");
+static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
+                         double* xhat, double* xp, double* z, int sub_b) {
+  if (mode == 0 && c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
+    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
+  TvFwdP p;
+  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
+  p.tiles_x = (p.W + TV_TW - 1) / TV_TW; p.tiles_y = (p.H + TV_TH - 1) / TV_TH;
+  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp; p.b = c->b; p.z = z;
+  p.tau = tau; p.sub_b = sub_b;
+  const unsigned grid = p.tiles_x * p.tiles_y;
+  FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
+  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
+  t_begin(c, FH_K_FWD);
+  if (mode != 0) k_fwd_tv<1, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fwd_tv<0, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  t_end(c, FH_K_FWD);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
-static int launch_adj_tv(fh_ctx* c, const AdjIO&) {
-  (void)c; return fail(FH_E_STATE, "stencil operator kernels not built yet");
+
+static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
+  TvAdjP p;
+  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
+  p.tiles_x = (p.W + TV_TW - 1) / TV_TW; p.tiles_y = (p.H + TV_TH - 1) / TV_TH;
+  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.accel = io.accel; p.coef = io.coef;
+  p.mode = io.mode; p.tau = io.tau;
+  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
+  const unsigned grid = p.tiles_x * p.tiles_y;
+  FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
+  p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
+  t_begin(c, FH_K_ADJ);
+  k_adj_tv<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  t_end(c, FH_K_ADJ);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // ---- operator-generic wrappers ---------------------------------------------------------------------

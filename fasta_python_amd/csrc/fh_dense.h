@@ -41,31 +41,6 @@ struct FwdP {
   double* out;          // device scalar block (FH_S_* layout)
 };
 
-// scalar slots (mirror include/fasta_hip.h enum fh_scalar)
-enum { S_FSQ = 0, S_DXG0 = 1, S_DX2 = 2, S_XH2 = 3, S_G02 = 4, S_GSUM = 5, S_GMAX = 6, S_RDOT = 7,
-       S_DXDG = 8, S_DG2 = 9, S_FSQ_ADJ = 10, S_XH2_ADJ = 11, S_GSUM_ADJ = 12, S_GMAX_ADJ = 13, S_ALPHA = 14 };
-
-// Reduce K running values over the workgroup; slot `maxslot` (or -1) uses max instead of +.
-// Result valid in thread 0.  `scr` = 4*K doubles of LDS.
-template <int K>
-__device__ __forceinline__ void block_reduce(double (&v)[K], double* scr, int maxslot) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    v[k] = (k == maxslot) ? wave_max(v[k]) : wave_sum(v[k]);
-    if (lane == 0) scr[wave * K + k] = v[k];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k == maxslot) v[k] = fmax(fmax(scr[k], scr[K + k]), fmax(scr[2 * K + k], scr[3 * K + k]));
-      else v[k] = ((scr[k] + scr[K + k]) + scr[2 * K + k]) + scr[3 * K + k];
-    }
-  }
-  __syncthreads();
-}
-
 // xprox pair for 16-byte piece c.  KIND = PX_PLAIN: xprox := x0 (fh_init / fh_apply / Lipschitz probes).
 template <int KIND>
 __device__ __forceinline__ d2 xprox_pair(const FwdP& p, uint32_t c, double level) {
