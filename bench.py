@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--m", type=int, default=65536, help="total rows of A (default: BASELINE config 2)")
     ap.add_argument("--n", type=int, default=65536)
-    ap.add_argument("--prox", default="shrink", choices=["shrink", "nonneg"])
+    ap.add_argument("--workload", default="lasso", choices=["lasso", "nnls", "tv"],
+                    help="lasso = BASELINE config 2 (default, the headline); nnls = config 3; tv = config 4 (8192^2 image)")
+    ap.add_argument("--image", type=int, default=8192, help="TV image side (workload tv)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=8192)
     ap.add_argument("--cpu-iters", type=int, default=4)
@@ -117,16 +119,91 @@ def cpu_baseline(A_map, b, mu, n, m_total, sample_rows, iters):
     }
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_pmc_summary.json, produced by scripts/profile_bench.sh + summarize_profile.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        data = json.load(fh)
+    for name, rec in data["kernels"].items():
+        if kernel_substr in name:
+            return rec["traffic_bytes"], os.path.basename(files[-1])
+    return None, None
+
+
+def run_tv(args, grp):
+    """BASELINE config 4: TV denoising dual on an image of side --image, 1 GPU."""
+    from fasta_python_amd.examples.tv_denoising import checkerboard
+    side = args.image
+    np.random.seed(7)
+    M = checkerboard(side, side, max(1, side // 32))
+    M += 0.1 * np.random.standard_normal(M.shape)
+    mu = 0.1
+    A = fa.GradDivMap(M.shape, device=grp.local_rank)
+    ctx = A.ctx
+    loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+    total = args.warmup + args.steps
+    solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=True, accelerate=False, verbose=False,
+                         max_iters=total, tolerance=0.0)
+    np.random.seed(3)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        solver.setup()
+        for _ in range(args.warmup):
+            solver.step()
+        ctx.timing_reset(); ctx.timing_enable(True)
+        bt0 = solver.total_backtracks
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            solver.step()
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.timing_enable(False)
+    elapsed = t1 - t0
+    P = side * side
+    fwd_ms, fwd_cnt = ctx.timing_get(hip.K_FWD)
+    adj_ms, adj_cnt = ctx.timing_get(hip.K_ADJ)
+    per = {"fasta_fwd(k_fwd_tv)": (fwd_ms, fwd_cnt, 64 * P), "fasta_adj(k_adj_tv)": (adj_ms, adj_cnt, 72 * P)}
+    dom = max(per, key=lambda k: per[k][0])
+    dms, dcnt, dbytes = per[dom]
+    achieved = dbytes / (dms / dcnt * 1e-3) / 1e9
+    result = {
+        "metric": "FBS iterations/sec, TV denoising dual (div/grad stencil, unit-ball prox)",
+        "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), adaptive FBS with backtracking",
+                   "backtracks_in_timed_steps": solver.total_backtracks - bt0, "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                     "avg_launch_ms": dms / dcnt, "algorithmic_bytes_per_launch": dbytes,
+                     "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1], "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9}
+                                    for k, v in per.items() if v[1]},
+                     "loop_GB/s_wallclock": (fwd_cnt * 64 * P + adj_cnt * 72 * P) / elapsed / 1e9},
+    }
+    print(json.dumps(result))
+    A.close()
+
+
 def main():
     args = parse()
     grp = Group()
+    if args.workload == "tv":
+        if grp.world != 1:
+            raise SystemExit("the TV workload is single-GPU (BASELINE config 4)")
+        return run_tv(args, grp)
+    args.prox = "nonneg" if args.workload == "nnls" else "shrink"
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={grp.world}: launch with torch.distributed.run")
     m_total, n = args.m, args.n
     assert m_total % grp.world == 0
     m_local = m_total // grp.world
     row0 = grp.rank * m_local
-    mu, sigma = 0.02, 0.01
+    mu, sigma = 0.02, (0.005 if args.workload == "nnls" else 0.01)     # nn_least_squares.py:49 uses 0.005
 
     tuning = {}
     for item in filter(None, args.tune.split(",")):
@@ -179,9 +256,12 @@ def main():
     dms, dcnt, dbytes = per[dom]
     achieved = dbytes / (dms / dcnt * 1e-3) / 1e9 if dcnt else 0.0
     loop_bytes = fwd_cnt * bytes_fwd + adj_cnt * bytes_adj
+    traffic, traffic_src = (pmc_traffic("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>")
+                            if (m_total, n, grp.world) == (65536, 65536, 1) else (None, None))
+    ceil_ms, ceil_bytes = ctx.stream_read_ms(2)
 
     result = {
-        "metric": "FBS iterations/sec, dense A m=n=65536, LASSO prox (fused GEMV+prox)",
+        "metric": "FBS iterations/sec + achieved HBM GB/s, dense A m=n=65536, LASSO prox",
         "value": args.steps / elapsed,
         "unit": "iterations/s",
         "n_gpus": grp.world,
@@ -193,12 +273,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"LASSO dense A {m_total}x{n} float64, soft-threshold prox, adaptive FBS with backtracking"
+        "config": {"workload": f"{'NNLS' if args.workload == 'nnls' else 'LASSO'} dense A {m_total}x{n} float64, "
+                               f"{'non-negativity' if args.workload == 'nnls' else 'soft-threshold'} prox, adaptive FBS with backtracking"
                                + (f", row-sharded over {grp.world} GPUs ({m_local} rows each)" if grp.world > 1 else ""),
                    "m": m_total, "n": n, "prox": args.prox, "mu": mu, "backtracks_in_timed_steps": backtracks,
                    "parallelism": f"row-shard x{grp.world}" if grp.world > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "stream_read_ceiling_GB/s": ceil_bytes / ceil_ms / 1e6,
                      "kernel": dom, "avg_launch_ms": dms / dcnt if dcnt else None,
                      "algorithmic_bytes_per_launch": dbytes,
                      "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1] if v[1] else None,

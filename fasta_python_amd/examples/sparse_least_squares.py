@@ -1,0 +1,43 @@
+"""min_x mu*||x||_1 + .5*||Ax - b||^2 (basis pursuit denoising) -- BASELINE configs 1, 2, 5.
+Recipe: fasta/examples/sparse_least_squares.py:41-44 (closures), :50-76 (construct)."""
+
+import numpy as np
+from numpy import linalg as la
+
+from .. import DenseMatrixMap, LeastSquares, Shrink, fasta
+from . import ExampleProblem, test_modes
+
+__all__ = ["SparseLeastSquaresProblem"]
+
+
+class SparseLeastSquaresProblem(ExampleProblem):
+    def __init__(self, A, At, b, mu, x=None):
+        self.A = A if isinstance(A, DenseMatrixMap) else DenseMatrixMap(np.asarray(A))
+        self.At = self.A.H
+        self.b, self.mu, self.x = b, mu, x
+
+    def solve(self, x0, fasta_options=None):
+        loss, reg = LeastSquares(self.b), Shrink(self.mu)
+        opts = dict(verbose=False)
+        opts.update(fasta_options or {})
+        c = fasta(self.A, self.At, loss.f, loss.gradf, reg.g, reg.prox, x0, **opts)
+        return c.solution, c
+
+    @staticmethod
+    def construct(M=200, N=1000, K=10, sigma=0.01, mu=0.02, seed=None):
+        if seed is not None:
+            np.random.seed(seed)
+        x = np.zeros(N)
+        x[np.random.permutation(N)[:K]] = 1
+        A = np.random.randn(M, N)
+        A /= la.norm(A, 2)
+        b = A @ x + sigma * np.random.randn(M)
+        return SparseLeastSquaresProblem(A, A.T, b, mu, x=x), np.zeros(N)
+
+
+if __name__ == "__main__":
+    problem, x0 = SparseLeastSquaresProblem.construct()
+    print("Constructed sparse least squares problem.")
+    adaptive, accelerated, plain = test_modes(problem, x0)
+    print("recovery error ||x - x_true||_inf = {:.3e}".format(np.abs(adaptive[0] - problem.x).max()))
+    problem.close()

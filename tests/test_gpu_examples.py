@@ -1,0 +1,82 @@
+"""The example harness on the HIP path (BASELINE config 1: 512x1024 sparse least squares through
+`fasta.examples`), compared with the oracle on the same seeded instance."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_modes(P):
+    out = []
+    for adaptive, accelerate in ((True, False), (False, True), (False, False)):
+        np.random.seed(77)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out.append(fo.fasta(*P.args7(), tolerance=1e-5, evaluate_objective=True, adaptive=adaptive,
+                                accelerate=accelerate))
+    return out
+
+
+def test_config1_sparse_least_squares_through_examples_package(capsys):
+    import fasta                                        # the drop-in name
+    from fasta.examples import test_modes
+    from fasta.examples.sparse_least_squares import SparseLeastSquaresProblem
+    problem, x0 = SparseLeastSquaresProblem.construct(M=512, N=1024, K=10, seed=21)
+    np.random.seed(21)
+    P = pr.sparse_least_squares(M=512, N=1024, K=10)
+    assert np.array_equal(P.data["b"], problem.b)       # same instance as the reference recipe would draw
+    want = _oracle_modes(P)
+
+    class Seeded(type(problem)):
+        def solve(self, x0, fasta_options=None):
+            np.random.seed(77)
+            return super().solve(x0, fasta_options)
+    problem.__class__ = Seeded
+    got = test_modes(problem, x0)
+    problem.close()
+    assert "Completed in" in capsys.readouterr().out
+    for (sol, c), w in zip(got, want):
+        assert isinstance(c, fasta.Convergence)
+        assert c.iteration_count == w.iteration_count and c.backtracks == w.backtracks
+        k = c.iteration_count
+        np.testing.assert_allclose(c.residuals[:k], w.residuals[:k], rtol=1e-6)
+        np.testing.assert_allclose(c.objectives[:k + 1], w.objectives[:k + 1], rtol=1e-8)
+        np.testing.assert_allclose(sol, w.solution, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("module,cls,kw", [
+    ("nn_least_squares", "NNLeastSquaresProblem", dict(M=300, N=200, seed=3)),
+    ("lasso", "LASSOProblem", dict(M=100, N=300, seed=4)),
+    ("tv_denoising", "TVDenoisingProblem", dict(shape=(64, 80), square=16, seed=5)),
+])
+def test_other_examples_run_and_converge(module, cls, kw):
+    import importlib
+    mod = importlib.import_module("fasta_python_amd.examples." + module)
+    problem, x0 = getattr(mod, cls).construct(**kw)
+    try:
+        sol, c = problem.solve(x0, {"tolerance": 1e-4, "max_iters": 400, "evaluate_objective": True})
+        assert c.iteration_count >= 1 and np.all(np.isfinite(sol))
+        obj = c.objectives[:c.iteration_count + 1]
+        assert obj[-1] <= obj[0]
+    finally:
+        problem.close()
+
+
+def test_verbose_output_format(capsys):
+    """fasta/__init__.py:118-120, :302-306 -- header and one line per iteration."""
+    import fasta_python_amd as fa
+    rng = np.random.RandomState(0)
+    A = rng.randn(20, 30) / 10
+    ls, reg = fa.LeastSquares(rng.randn(20)), fa.Shrink(0.01)
+    np.random.seed(0)
+    c = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(30), max_iters=3, tolerance=0.0)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "Initializing FASTA..."
+    assert out[2] == "Iteration #\tResidual\tStepsize\tAccel. param\tBacktracks\tObjective"
+    assert out[3].startswith("[0     ]\t") and len(out[3].split("\t")) == 6
+    assert c.iteration_count == 3

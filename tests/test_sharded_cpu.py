@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the N>1 path on CPU: rendezvous plumbing of bench.py and the row-sharding
+arithmetic (one all-reduce of the A^T partial sums per iteration, all-reduced ||r||^2 for the line search)."""
+import os
+import socket
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "accelerated"])
+def test_two_rank_row_sharding_matches_single_rank(tmp_path, mode):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+
+    np.random.seed(5)
+    P = pr.sparse_least_squares(M=96, N=160, K=6)
+    opts = dict(tolerance=1e-6, evaluate_objective=True, record_iterates=True,
+                adaptive=(mode != "accelerated"), accelerate=(mode == "accelerated"))
+    np.random.seed(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # every rank takes the same branches and holds the same replicated iterate
+    for key in ("residuals", "stepsizes", "objectives", "solution", "iteration_count", "backtracks"):
+        assert np.array_equal(r0[key], r1[key]), key
+    assert int(r0["iteration_count"]) == want.iteration_count and int(r0["backtracks"]) == want.backtracks
+    k = want.iteration_count
+    np.testing.assert_allclose(r0["residuals"][:k], want.residuals[:k], rtol=1e-8)
+    np.testing.assert_allclose(r0["objectives"][:k + 1], want.objectives[:k + 1], rtol=1e-10)
+    np.testing.assert_allclose(r0["iterates"][:k + 1], want.iterates[:k + 1], rtol=1e-8, atol=1e-12)
+
+
+def test_row_partition_of_bench_covers_matrix_once():
+    m_total = 65536
+    for world in (1, 2, 4, 8):
+        rows = [(r * (m_total // world), m_total // world) for r in range(world)]
+        assert sum(c for _, c in rows) == m_total
+        assert [s for s, _ in rows] == list(range(0, m_total, m_total // world))
