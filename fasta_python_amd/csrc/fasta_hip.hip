@@ -513,6 +513,7 @@ static void launch_adj_c(fh_ctx* c, const AdjP& p, unsigned grid) {
 struct AdjIO {
   const double* z; const double* zacc0; int sub_b; int accel; double coef; int mode; double tau;
   const double* x0; const double* xp; const double* xacc0; const double* xhat; double* x1; double* g1;
+  const double* g0;   // stencil path only: K-adj recomputes xhat = x0 - tau*g0
 };
 
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
@@ -609,14 +610,16 @@ static int launch_level_search(fh_ctx* c, double tau) {
 
 static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                          double* xhat, double* xp, double* z, int sub_b) {
+  (void)xhat;   // the stencil path never materialises xhat: K-adj recomputes x0 - tau*g0 bit-identically
   if (mode == 0 && c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
     return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
   TvFwdP p;
   p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.tiles_x = (p.W + TV_TW - 1) / TV_TW; p.tiles_y = (p.H + TV_TH - 1) / TV_TH;
-  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp; p.b = c->b; p.z = z;
+  const uint32_t strips = (p.W + TV_SW - 1) / TV_SW;
+  p.strip_groups = (strips + 3) / 4;
+  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xp = xp; p.b = c->b; p.z = z;
   p.tau = tau; p.sub_b = sub_b;
-  const unsigned grid = p.tiles_x * p.tiles_y;
+  const unsigned grid = p.strip_groups * ((p.H + TV_ROWS - 1) / TV_ROWS);
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
@@ -631,11 +634,13 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
 static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   TvAdjP p;
   p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.tiles_x = (p.W + TV_TW - 1) / TV_TW; p.tiles_y = (p.H + TV_TH - 1) / TV_TH;
+  const uint32_t strips = (p.W + TV_SW - 1) / TV_SW;
+  p.strip_groups = (strips + 3) / 4;
   p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.accel = io.accel; p.coef = io.coef;
   p.mode = io.mode; p.tau = io.tau;
-  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
-  const unsigned grid = p.tiles_x * p.tiles_y;
+  p.x0 = io.x0; p.g0 = io.g0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.g1 = io.g1;
+  if (p.mode == 0 && !p.g0) return fail(FH_E_STATE, "stencil adjoint epilogue needs g0");
+  const unsigned grid = p.strip_groups * ((p.H + TV_ROWS - 1) / TV_ROWS);
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
   t_begin(c, FH_K_ADJ);
@@ -742,7 +747,7 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
   io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
   io.mode = 0; io.tau = tau;
   io.x0 = c->X[c->xc]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-  io.x1 = c->X[c->xc ^ 1]; io.g1 = c->G[c->gc ^ 1];
+  io.x1 = c->X[c->xc ^ 1]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
   c->last_accel = accel != 0;
   FH_TRY(op_adj(c, io));
   return fetch_scalars(c, scalars);

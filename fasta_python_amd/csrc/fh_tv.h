@@ -5,23 +5,29 @@
 //   grad(X)[i,j,0] =  X[i-1,j] - X[i,j] ;  grad(X)[i,j,1] = X[i,j-1] - X[i,j]  (np.roll(.., +1), :38)
 //
 // Layout: Y-space vectors are pixel-interleaved float64 pairs (C order of (H,W,2)): one pixel = one
-// aligned 16-byte access; X-space vectors are H*W float64.  A workgroup owns a TH x TW pixel tile.
-//   K-fwd: forward point + unit-ball prox (examples/tv_denoising.py:89-96) for the tile PLUS a one-pixel
-//          halo below/right (recomputed, 7 % extra arithmetic, the loads hit L2), staged in LDS; then
-//          z = div(xprox) from LDS, r = z - b, and the line-search reductions.  Algorithmic HBM bytes
-//          64*P: read Y0,G0 (32P) + b (8P), write xhat? no -- see DESIGN.md.
-//   K-adj: r = z' - b for the tile plus a halo above/left in LDS, g1 = grad(r), BB epilogue.
+// aligned 16-byte access; X-space vectors are H*W float64.
+//
+// Wave-strip streaming, no LDS tiles and no barriers in the hot loop: each 64-lane wave owns a strip of
+// 63 image columns (lane 63 / lane 0 is a recomputed halo column) and walks TV_ROWS rows top to bottom.
+// The vertical neighbour is the previous row's value kept in a register, the horizontal neighbour comes
+// from the adjacent lane by __shfl; loads are issued TV_U rows ahead (2-3 x 16 B per lane per row).
+//   K-fwd: xhat = y0 - tau*g0, xprox = xhat / max(||xhat||_2, 1) per pixel (tv_denoising.py:89-96),
+//          z = div(xprox), ||z-b||^2 and the line-search reductions.  xhat is NOT written (K-adj
+//          recomputes it from y0, g0 bit-identically).  HBM bytes: reads 16+16+8, writes 16+8 = 64*P.
+//   K-adj: r = z' - b, g1 = grad(r), Dg / BB reductions (+ FISTA extrapolation).
+//          HBM bytes: reads 8+8 (z,b) + 16*3 (y0,g0,xprox), writes 16 = 80*P  (SURVEY model: 72*P).
 #pragma once
 #include "fh_device.h"
 
-#define TV_TH 16
-#define TV_TW 128
+#define TV_ROWS 64     // rows per workgroup
+#define TV_SW 63       // owned columns per wave
+#define TV_U 4         // rows of loads in flight
 
 struct TvFwdP {
   uint32_t H, W;
-  uint32_t tiles_x, tiles_y;
+  uint32_t strip_groups;      // ceil(ceil(W/63)/4): 4 wave strips per workgroup
   const double* x0; const double* g0; const double* xacc0;   // (H,W,2)
-  double* xhat; double* xp;                                   // (H,W,2)
+  double* xp;                                                 // (H,W,2)
   const double* b; double* z;                                 // (H,W)
   double tau;
   int sub_b;
@@ -47,96 +53,113 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
 // (IDENT = 1 swaps the prox for the identity: plain gradient descent on the dual).
 template <int PLAIN, int IDENT>
 __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
-  __shared__ __attribute__((aligned(16))) d2 s_y[(TV_TH + 1) * (TV_TW + 1)];
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t ty = blockIdx.x / p.tiles_x, tx = blockIdx.x % p.tiles_x;
-  const uint32_t i0 = ty * TV_TH, j0 = tx * TV_TW;
-  const uint32_t rows = min((uint32_t)TV_TH, p.H - i0), cols = min((uint32_t)TV_TW, p.W - j0);
-  const uint32_t span = cols + 1u;
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum(unused), gmax(unused), rdot
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * TV_ROWS;
+  const uint32_t rows = min((uint32_t)TV_ROWS, p.H - i0);
+  const uint32_t c = (sg * 4u + wave) * TV_SW + lane;     // image column this lane loads
+  const bool own = lane < TV_SW && c < p.W;               // lane 63 (and columns past W) only feed neighbours
+  const uint32_t cl = c % p.W;                            // periodic wrap for the halo column
+  double v[5] = {0, 0, 0, 0, 0};                          // dxg0, dx2, xh2, g02, rdot
+  double fs = 0.0;
 
-  // ---- phase 1: prox'd tile + halo (row `rows` = next row, column `cols` = next column, periodic) ----
-  for (uint32_t t = tid; t < (rows + 1u) * span; t += FH_WG) {
-    const uint32_t r = t / span, c = t % span;
-    uint32_t gi = i0 + r; if (gi >= p.H) gi -= p.H;
-    uint32_t gj = j0 + c; if (gj >= p.W) gj -= p.W;
-    const uint64_t pix = (uint64_t)gi * p.W + gj;
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[pix];
-    d2 xp = x0v;
-    if (!PLAIN) {
-      const d2 g0v = reinterpret_cast<const d2*>(p.g0)[pix];
-      d2 xh;
-      xh.x = fwd_point(x0v.x, g0v.x, p.tau);
-      xh.y = fwd_point(x0v.y, g0v.y, p.tau);
-      xp = IDENT ? xh : tv_ball(xh);
-      if (r < rows && c < cols) {        // interior pixel: this workgroup owns its outputs and reductions
-        reinterpret_cast<d2*>(p.xhat)[pix] = xh;
-        reinterpret_cast<d2*>(p.xp)[pix] = xp;
-        d2 xav = {0.0, 0.0};
-        if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
+  // prox'd pixel of image row `row` in this lane's column, from raw loads; owner side effects when `mine`
+  auto finish = [&](d2 x0v, d2 g0v, uint64_t pix, bool mine) -> d2 {
+    if (PLAIN) return x0v;
+    d2 xh;
+    xh.x = fwd_point(x0v.x, g0v.x, p.tau);
+    xh.y = fwd_point(x0v.y, g0v.y, p.tau);
+    const d2 xp = IDENT ? xh : tv_ball(xh);
+    if (mine) {
+      reinterpret_cast<d2*>(p.xp)[pix] = xp;
+      d2 xav = {0.0, 0.0};
+      if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const double dx = sub_nofma(xp[e], x0v[e]);
-          const double dh = sub_nofma(xp[e], xh[e]);
-          v[0] = fma(dx, g0v[e], v[0]);
-          v[1] = fma(dx, dx, v[1]);
-          v[2] = fma(dh, dh, v[2]);
-          v[3] = fma(g0v[e], g0v[e], v[3]);
-          v[6] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], xav[e]), v[6]);
-        }
+      for (int e = 0; e < 2; ++e) {
+        const double dx = sub_nofma(xp[e], x0v[e]);
+        const double dh = sub_nofma(xp[e], xh[e]);
+        v[0] = fma(dx, g0v[e], v[0]);
+        v[1] = fma(dx, dx, v[1]);
+        v[2] = fma(dh, dh, v[2]);
+        v[3] = fma(g0v[e], g0v[e], v[3]);
+        v[4] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], xav[e]), v[4]);
       }
     }
-    s_y[r * (TV_TW + 1) + c] = xp;
-  }
-  __syncthreads();
+    return xp;
+  };
 
-  // ---- phase 2: z = div(xprox) from LDS, residual, f partial ----------------------------------------
-  double fs = 0.0;
-  for (uint32_t t = tid; t < rows * cols; t += FH_WG) {
-    const uint32_t r = t / cols, c = t % cols;
-    const d2 me = s_y[r * (TV_TW + 1) + c];
-    const double dn = s_y[(r + 1) * (TV_TW + 1) + c].x;
-    const double rt = s_y[r * (TV_TW + 1) + c + 1].y;
-    double zv;
-    {
-#pragma clang fp contract(off)
-      const double t0 = dn - me.x;        // roll(Y0, -1, axis 0) - Y0
-      const double t1 = rt - me.y;        // roll(Y1, -1, axis 1) - Y1
-      zv = t0 + t1;
-    }
-    const uint64_t pix = (uint64_t)(i0 + r) * p.W + (j0 + c);
-    p.z[pix] = zv;
-    const double rv = p.sub_b ? sub_nofma(zv, p.b[pix]) : zv;
-    fs = fma(rv, rv, fs);
+  d2 cur;
+  {
+    const uint64_t pix = (uint64_t)i0 * p.W + cl;
+    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[pix];
+    d2 g0v = {0.0, 0.0};
+    if (!PLAIN) g0v = reinterpret_cast<const d2*>(p.g0)[pix];
+    cur = finish(x0v, g0v, pix, own);
   }
-  double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+  for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
+    d2 xv[TV_U], gv[TV_U];
+    double bv[TV_U];
+    uint64_t npix[TV_U];
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      const uint32_t rr = min(r0 + u + 1u, rows);                 // row below output row r0+u (clamped past the chunk)
+      uint32_t nrow = i0 + rr; if (nrow >= p.H) nrow -= p.H;      // periodic
+      npix[u] = (uint64_t)nrow * p.W + cl;
+      xv[u] = reinterpret_cast<const d2*>(p.x0)[npix[u]];
+      gv[u] = (d2){0.0, 0.0};
+      if (!PLAIN) gv[u] = reinterpret_cast<const d2*>(p.g0)[npix[u]];
+      const uint32_t orow = min(i0 + r0 + u, p.H - 1u);
+      bv[u] = (p.sub_b && own) ? p.b[(uint64_t)orow * p.W + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      if (r0 + u < rows) {                                        // wave-uniform
+        const d2 nxt = finish(xv[u], gv[u], npix[u], own && (r0 + u + 1u < rows));
+        const double right_y = __shfl_down(cur.y, 1, 64);        // pixel (row, col+1), component 1
+        double zv;
+        {
+#pragma clang fp contract(off)
+          const double t0 = nxt.x - cur.x;                        // roll(Y0, -1, axis 0) - Y0
+          const double t1 = right_y - cur.y;                      // roll(Y1, -1, axis 1) - Y1
+          zv = t0 + t1;
+        }
+        if (own) {
+          p.z[(uint64_t)(i0 + r0 + u) * p.W + c] = zv;
+          const double rv = p.sub_b ? sub_nofma(zv, bv[u]) : zv;
+          fs = fma(rv, rv, fs);
+        }
+        cur = nxt;
+      }
+    }
+  }
+  double w[8] = {fs, v[0], v[1], v[2], v[3], 0.0, 0.0, v[4]};   // S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, -, -, S_RDOT
   block_reduce<8>(w, s_scr, -1);
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) p.red[(uint64_t)blockIdx.x * 8 + k] = w[k];
   }
   if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
-  double u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) u[k] += p.red[(uint64_t)i * 8 + k];
+    for (int k = 0; k < 8; ++k) t[k] += p.red[(uint64_t)i * 8 + k];
   }
-  block_reduce<8>(u, s_scr, -1);
+  block_reduce<8>(t, s_scr, -1);
   if (tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) p.out[k] = u[k];     // S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, S_GSUM, S_GMAX, S_RDOT
+    for (int k = 0; k < 8; ++k) p.out[k] = t[k];
     __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 struct TvAdjP {
   uint32_t H, W;
-  uint32_t tiles_x, tiles_y;
+  uint32_t strip_groups;
   const double* z; const double* zacc0; const double* b;
   int sub_b; int accel; double coef; int mode; double tau;
-  const double* x0; const double* xp; const double* xacc0; const double* xhat;
+  const double* x0; const double* g0; const double* xp; const double* xacc0;
   double* x1; double* g1;
   double* red;          // [grid][8]
   unsigned* counter;
@@ -144,63 +167,80 @@ struct TvAdjP {
 };
 
 __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
-  __shared__ __attribute__((aligned(16))) double s_r[(TV_TH + 1) * (TV_TW + 1)];
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t ty = blockIdx.x / p.tiles_x, tx = blockIdx.x % p.tiles_x;
-  const uint32_t i0 = ty * TV_TH, j0 = tx * TV_TW;
-  const uint32_t rows = min((uint32_t)TV_TH, p.H - i0), cols = min((uint32_t)TV_TW, p.W - j0);
-  const uint32_t span = cols + 1u;
-
-  // ---- phase 1: residual r = z' - b for the tile plus the halo row above / column left (periodic) -----
-  // LDS row 0 / column 0 hold the halo; tile pixel (r,c) sits at (r+1, c+1).
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * TV_ROWS;
+  const uint32_t rows = min((uint32_t)TV_ROWS, p.H - i0);
+  // lane 0 is the left halo: column (first owned column - 1), periodic
+  const uint32_t first = (sg * 4u + wave) * TV_SW;
+  const uint32_t c = first + lane - 1u;                    // wraps to 0xFFFFFFFF for first == 0, lane == 0
+  const bool own = lane >= 1u && c < p.W;
+  const uint32_t cl = (lane == 0u) ? (first == 0u ? p.W - 1u : (first - 1u) % p.W) : c % p.W;
+  double v[5] = {0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax
   double fs = 0.0;
-  for (uint32_t t = tid; t < (rows + 1u) * span; t += FH_WG) {
-    const uint32_t r = t / span, c = t % span;
-    const uint32_t gi = (r == 0) ? (i0 == 0 ? p.H - 1u : i0 - 1u) : i0 + r - 1u;
-    const uint32_t gj = (c == 0) ? (j0 == 0 ? p.W - 1u : j0 - 1u) : j0 + c - 1u;
-    const uint64_t pix = (uint64_t)gi * p.W + gj;
+
+  auto resid = [&](uint64_t pix) -> double {
     double zv = p.z[pix];
     if (p.accel) zv = extrapolate(zv, p.zacc0[pix], p.coef);
-    const double rv = p.sub_b ? sub_nofma(zv, p.b[pix]) : zv;
-    s_r[r * (TV_TW + 1) + c] = rv;
-    if (r > 0 && c > 0) fs = fma(rv, rv, fs);
-  }
-  __syncthreads();
+    return p.sub_b ? sub_nofma(zv, p.b[pix]) : zv;
+  };
 
-  // ---- phase 2: g1 = grad(r), n-side epilogue ---------------------------------------------------------
-  double v[5] = {0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax
-  for (uint32_t t = tid; t < rows * cols; t += FH_WG) {
-    const uint32_t r = t / cols, c = t % cols;
-    const double me = s_r[(r + 1) * (TV_TW + 1) + c + 1];
-    d2 g;
-    g.x = sub_nofma(s_r[r * (TV_TW + 1) + c + 1], me);         // roll(X, +1, axis 0) - X
-    g.y = sub_nofma(s_r[(r + 1) * (TV_TW + 1) + c], me);       // roll(X, +1, axis 1) - X
-    const uint64_t pix = (uint64_t)(i0 + r) * p.W + (j0 + c);
-    reinterpret_cast<d2*>(p.g1)[pix] = g;
-    if (p.mode == 0) {
-      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[pix];
-      const d2 xpv = reinterpret_cast<const d2*>(p.xp)[pix];
-      const d2 xhv = reinterpret_cast<const d2*>(p.xhat)[pix];
-      d2 xav = {0.0, 0.0};
-      if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
-      d2 x1v;
+  double up;
+  {
+    const uint32_t prow = (i0 == 0u) ? p.H - 1u : i0 - 1u;
+    up = resid((uint64_t)prow * p.W + cl);
+  }
+  for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
+    double me[TV_U];
+    d2 x0v[TV_U], g0v[TV_U], xpv[TV_U], xav[TV_U];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        double x1 = xpv[e];
-        if (p.accel) x1 = extrapolate(xpv[e], xav[e], p.coef);
-        const double dx = sub_nofma(xpv[e], x0v[e]);
-        const double dg = bb_dgrad(g[e], xhv[e], x0v[e], p.tau);
-        const double dh = sub_nofma(x1, xhv[e]);
-        v[0] = fma(dx, dg, v[0]);
-        v[1] = fma(dg, dg, v[1]);
-        v[2] = fma(dh, dh, v[2]);
-        v[3] += fabs(x1);
-        v[4] = fmax(v[4], fabs(x1));
-        x1v[e] = x1;
+    for (int u = 0; u < TV_U; ++u) {
+      const uint32_t row = min(i0 + r0 + u, p.H - 1u);
+      const uint64_t pix = (uint64_t)row * p.W + cl;
+      me[u] = resid(pix);
+      if (p.mode == 0) {
+        x0v[u] = reinterpret_cast<const d2*>(p.x0)[pix];
+        g0v[u] = reinterpret_cast<const d2*>(p.g0)[pix];
+        xpv[u] = reinterpret_cast<const d2*>(p.xp)[pix];
+        xav[u] = (d2){0.0, 0.0};
+        if (p.accel) xav[u] = reinterpret_cast<const d2*>(p.xacc0)[pix];
       }
-      if (p.accel) reinterpret_cast<d2*>(p.x1)[pix] = x1v;
+    }
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      if (r0 + u < rows) {                                       // wave-uniform
+        const double left = __shfl_up(me[u], 1, 64);             // residual at (row, col-1)
+        d2 g;
+        g.x = sub_nofma(up, me[u]);                              // roll(X, +1, axis 0) - X
+        g.y = sub_nofma(left, me[u]);                            // roll(X, +1, axis 1) - X
+        if (own) {
+          const uint64_t pix = (uint64_t)(i0 + r0 + u) * p.W + c;
+          fs = fma(me[u], me[u], fs);
+          reinterpret_cast<d2*>(p.g1)[pix] = g;
+          if (p.mode == 0) {
+            d2 x1v;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const double xh = fwd_point(x0v[u][e], g0v[u][e], p.tau);   // same bits as K-fwd's xhat
+              double x1 = xpv[u][e];
+              if (p.accel) x1 = extrapolate(xpv[u][e], xav[u][e], p.coef);
+              const double dx = sub_nofma(xpv[u][e], x0v[u][e]);
+              const double dg = bb_dgrad(g[e], xh, x0v[u][e], p.tau);
+              const double dh = sub_nofma(x1, xh);
+              v[0] = fma(dx, dg, v[0]);
+              v[1] = fma(dg, dg, v[1]);
+              v[2] = fma(dh, dh, v[2]);
+              v[3] += fabs(x1);
+              v[4] = fmax(v[4], fabs(x1));
+              x1v[e] = x1;
+            }
+            if (p.accel) reinterpret_cast<d2*>(p.x1)[pix] = x1v;
+          }
+        }
+        up = me[u];
+      }
     }
   }
   double w[6] = {v[0], v[1], v[2], v[3], v[4], fs};
@@ -210,18 +250,18 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
     for (int k = 0; k < 6; ++k) p.red[(uint64_t)blockIdx.x * 8 + k] = w[k];
   }
   if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
-  double u[6] = {0, 0, 0, 0, 0, 0};
+  double t[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double t = p.red[(uint64_t)i * 8 + k];
-      if (k == 4) u[k] = fmax(u[k], t); else u[k] += t;
+      const double q = p.red[(uint64_t)i * 8 + k];
+      if (k == 4) t[k] = fmax(t[k], q); else t[k] += q;
     }
   }
-  block_reduce<6>(u, s_scr, 4);
+  block_reduce<6>(t, s_scr, 4);
   if (tid == 0) {
-    p.out[S_DXDG] = u[0]; p.out[S_DG2] = u[1]; p.out[S_XH2_ADJ] = u[2]; p.out[S_GSUM_ADJ] = u[3];
-    p.out[S_GMAX_ADJ] = u[4]; p.out[S_FSQ_ADJ] = u[5];
+    p.out[S_DXDG] = t[0]; p.out[S_DG2] = t[1]; p.out[S_XH2_ADJ] = t[2]; p.out[S_GSUM_ADJ] = t[3];
+    p.out[S_GMAX_ADJ] = t[4]; p.out[S_FSQ_ADJ] = t[5];
     __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
