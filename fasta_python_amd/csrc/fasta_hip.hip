@@ -133,6 +133,8 @@ struct fh_ctx {
   int adj_cpt = 0;           // 0 = auto
   int ld_pad = 0;
   int nt_loads = 1;
+  int tv_u = 4;
+  int tv_rows = 64;
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
@@ -302,6 +304,12 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       c->ld_pad = (int)value; return 0;
     case FH_TUNE_NT_LOADS:
       c->nt_loads = value ? 1 : 0; return 0;
+    case FH_TUNE_TV_U:
+      if (value != 2 && value != 4 && value != 8) return fail(FH_E_ARG, "TV_U must be 2, 4 or 8");
+      c->tv_u = (int)value; return 0;
+    case FH_TUNE_TV_ROWS:
+      if (value < 1 || value > 4096) return fail(FH_E_ARG, "TV_ROWS must be in [1,4096]");
+      c->tv_rows = (int)value; return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
   }
 }
@@ -619,13 +627,19 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   p.strip_groups = (strips + 3) / 4;
   p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xp = xp; p.b = c->b; p.z = z;
   p.tau = tau; p.sub_b = sub_b;
-  const unsigned grid = p.strip_groups * ((p.H + TV_ROWS - 1) / TV_ROWS);
+  p.rows_wg = (uint32_t)c->tv_rows;
+  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
-  if (mode != 0) k_fwd_tv<1, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_fwd_tv<0, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+#define TV_FWD(U)                                                                                          \
+  do {                                                                                                     \
+    if (mode != 0) k_fwd_tv<1, 0, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                        \
+    else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p); \
+    else k_fwd_tv<0, 1, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
+  } while (0)
+  if (c->tv_u == 2) TV_FWD(2); else if (c->tv_u == 8) TV_FWD(8); else TV_FWD(4);
+#undef TV_FWD
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -640,11 +654,14 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   p.mode = io.mode; p.tau = io.tau;
   p.x0 = io.x0; p.g0 = io.g0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.g1 = io.g1;
   if (p.mode == 0 && !p.g0) return fail(FH_E_STATE, "stencil adjoint epilogue needs g0");
-  const unsigned grid = p.strip_groups * ((p.H + TV_ROWS - 1) / TV_ROWS);
+  p.rows_wg = (uint32_t)c->tv_rows;
+  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
   t_begin(c, FH_K_ADJ);
-  k_adj_tv<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_u == 2) k_adj_tv<2><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else if (c->tv_u == 8) k_adj_tv<8><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_adj_tv<4><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_ADJ);
   HIP_TRY(hipGetLastError());
   return 0;

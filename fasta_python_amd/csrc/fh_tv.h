@@ -19,13 +19,13 @@
 #pragma once
 #include "fh_device.h"
 
-#define TV_ROWS 64     // rows per workgroup
 #define TV_SW 63       // owned columns per wave
-#define TV_U 4         // rows of loads in flight
+// rows per workgroup (p.rows_wg) and rows of loads in flight (template TV_U) are tunables, see fh_set_tuning
 
 struct TvFwdP {
   uint32_t H, W;
   uint32_t strip_groups;      // ceil(ceil(W/63)/4): 4 wave strips per workgroup
+  uint32_t rows_wg;           // rows per workgroup
   const double* x0; const double* g0; const double* xacc0;   // (H,W,2)
   double* xp;                                                 // (H,W,2)
   const double* b; double* z;                                 // (H,W)
@@ -51,14 +51,14 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
 
 // PLAIN = 1: xprox := x0 (fh_init / fh_apply / Lipschitz probes); PLAIN = 0: FBS step with the TV-ball prox
 // (IDENT = 1 swaps the prox for the identity: plain gradient descent on the dual).
-template <int PLAIN, int IDENT>
+template <int PLAIN, int IDENT, int TV_U>
 __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
-  const uint32_t i0 = rc * TV_ROWS;
-  const uint32_t rows = min((uint32_t)TV_ROWS, p.H - i0);
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
   const uint32_t c = (sg * 4u + wave) * TV_SW + lane;     // image column this lane loads
   const bool own = lane < TV_SW && c < p.W;               // lane 63 (and columns past W) only feed neighbours
   const uint32_t cl = c % p.W;                            // periodic wrap for the halo column
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
 struct TvAdjP {
   uint32_t H, W;
   uint32_t strip_groups;
+  uint32_t rows_wg;
   const double* z; const double* zacc0; const double* b;
   int sub_b; int accel; double coef; int mode; double tau;
   const double* x0; const double* g0; const double* xp; const double* xacc0;
@@ -166,13 +167,14 @@ struct TvAdjP {
   double* out;
 };
 
+template <int TV_U>
 __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
-  const uint32_t i0 = rc * TV_ROWS;
-  const uint32_t rows = min((uint32_t)TV_ROWS, p.H - i0);
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
   // lane 0 is the left halo: column (first owned column - 1), periodic
   const uint32_t first = (sg * 4u + wave) * TV_SW;
   const uint32_t c = first + lane - 1u;                    // wraps to 0xFFFFFFFF for first == 0, lane == 0

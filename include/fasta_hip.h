@@ -84,7 +84,9 @@ enum fh_tuning_key {
   FH_TUNE_ADJ_SLAB_ROWS = 2, /* rows per K-adj slab (multiple of 8; 0 = auto)               */
   FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */
   FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
-  FH_TUNE_NT_LOADS = 5       /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
+  FH_TUNE_NT_LOADS = 5,      /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
+  FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads in flight per lane (2, 4, 8)           */
+  FH_TUNE_TV_ROWS = 7        /* stencil kernels: image rows per workgroup                            */
 };
 
 /* ---- library / context -------------------------------------------------------------- */
