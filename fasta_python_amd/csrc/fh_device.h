@@ -127,6 +127,29 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, v
   return *flag != 0u;
 }
 
+// Light hand-off for REDUCTION PARTIALS ONLY (K doubles per workgroup, all held by thread 0):
+// the partials go out as agent-scope relaxed atomic stores (write-through `sc1`), thread 0 drains them and
+// takes the ticket; the last workgroup reads them back with agent-scope relaxed atomic loads (`sc1`, served
+// past this CU's L1).  No release fence => no `buffer_wbl2` of the whole XCD L2, which matters in kernels
+// that dirty megabytes of their own output (the stencil kernels): their bulk stores are not part of the
+// hand-off and must not be flushed or waited for.  (CDNA4 guide, Guideline 16 / visibility table row 1.)
+template <int K>
+__device__ __forceinline__ bool publish_partials(double* slot, const double (&v)[K], unsigned* counter, unsigned total,
+                                                 volatile unsigned* flag) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) __hip_atomic_store(slot + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == total - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+__device__ __forceinline__ double load_partial(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 16-byte streaming load of A.  NT=1 marks it non-temporal (read-once stream; keeps x0/g0 in L2).
 template <int NT>
 __device__ __forceinline__ d2 load_stream(const d2* p) {

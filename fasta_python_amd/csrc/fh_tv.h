@@ -136,15 +136,11 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   }
   double w[8] = {fs, v[0], v[1], v[2], v[3], 0.0, 0.0, v[4]};   // S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, -, -, S_RDOT
   block_reduce<8>(w, s_scr, -1);
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) p.red[(uint64_t)blockIdx.x * 8 + k] = w[k];
-  }
-  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  if (!publish_partials<8>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
   double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] += p.red[(uint64_t)i * 8 + k];
+    for (int k = 0; k < 8; ++k) t[k] += load_partial(p.red + (uint64_t)i * 8 + k);
   }
   block_reduce<8>(t, s_scr, -1);
   if (tid == 0) {
@@ -247,16 +243,12 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   }
   double w[6] = {v[0], v[1], v[2], v[3], v[4], fs};
   block_reduce<6>(w, s_scr, 4);
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) p.red[(uint64_t)blockIdx.x * 8 + k] = w[k];
-  }
-  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  if (!publish_partials<6>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
   double t[6] = {0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double q = p.red[(uint64_t)i * 8 + k];
+      const double q = load_partial(p.red + (uint64_t)i * 8 + k);
       if (k == 4) t[k] = fmax(t[k], q); else t[k] += q;
     }
   }
