@@ -632,13 +632,14 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
-#define TV_FWD(U)                                                                                          \
-  do {                                                                                                     \
-    if (mode != 0) k_fwd_tv<1, 0, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                        \
-    else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p); \
-    else k_fwd_tv<0, 1, U><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
+#define TV_FWD(U, NT)                                                                                          \
+  do {                                                                                                         \
+    if (mode != 0) k_fwd_tv<1, 0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                        \
+    else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p); \
+    else k_fwd_tv<0, 1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-  if (c->tv_u == 2) TV_FWD(2); else if (c->tv_u == 8) TV_FWD(8); else TV_FWD(4);
+  if (c->nt_loads) { if (c->tv_u == 2) TV_FWD(2, 1); else if (c->tv_u == 8) TV_FWD(8, 1); else TV_FWD(4, 1); }
+  else { if (c->tv_u == 2) TV_FWD(2, 0); else if (c->tv_u == 8) TV_FWD(8, 0); else TV_FWD(4, 0); }
 #undef TV_FWD
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
@@ -659,9 +660,10 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
   t_begin(c, FH_K_ADJ);
-  if (c->tv_u == 2) k_adj_tv<2><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else if (c->tv_u == 8) k_adj_tv<8><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_adj_tv<4><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+#define TV_ADJ(U, NT) k_adj_tv<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
+  if (c->nt_loads) { if (c->tv_u == 2) TV_ADJ(2, 1); else if (c->tv_u == 8) TV_ADJ(8, 1); else TV_ADJ(4, 1); }
+  else { if (c->tv_u == 2) TV_ADJ(2, 0); else if (c->tv_u == 8) TV_ADJ(8, 0); else TV_ADJ(4, 0); }
+#undef TV_ADJ
   t_end(c, FH_K_ADJ);
   HIP_TRY(hipGetLastError());
   return 0;

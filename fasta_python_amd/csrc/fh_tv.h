@@ -8,9 +8,10 @@
 // aligned 16-byte access; X-space vectors are H*W float64.
 //
 // Wave-strip streaming, no LDS tiles and no barriers in the hot loop: each 64-lane wave owns a strip of
-// 63 image columns (lane 63 / lane 0 is a recomputed halo column) and walks TV_ROWS rows top to bottom.
-// The vertical neighbour is the previous row's value kept in a register, the horizontal neighbour comes
-// from the adjacent lane by __shfl; loads are issued TV_U rows ahead (2-3 x 16 B per lane per row).
+// 64 image columns (aligned 1 KiB row pieces) and walks `rows_wg` rows top to bottom.  The vertical
+// neighbour is the previous row's value kept in a register; the horizontal neighbour comes from the
+// adjacent lane by __shfl, and for the strip's edge lane from a halo pixel that lanes 0..TV_U-1 fetch
+// (one lane per row of the batch) and broadcast.  Loads are issued TV_U rows ahead.
 //   K-fwd: xhat = y0 - tau*g0, xprox = xhat / max(||xhat||_2, 1) per pixel (tv_denoising.py:89-96),
 //          z = div(xprox), ||z-b||^2 and the line-search reductions.  xhat is NOT written (K-adj
 //          recomputes it from y0, g0 bit-identically).  HBM bytes: reads 16+16+8, writes 16+8 = 64*P.
@@ -19,7 +20,7 @@
 #pragma once
 #include "fh_device.h"
 
-#define TV_SW 63       // owned columns per wave
+#define TV_SW 64       // owned columns per wave
 // rows per workgroup (p.rows_wg) and rows of loads in flight (template TV_U) are tunables, see fh_set_tuning
 
 struct TvFwdP {
@@ -51,7 +52,14 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
 
 // PLAIN = 1: xprox := x0 (fh_init / fh_apply / Lipschitz probes); PLAIN = 0: FBS step with the TV-ball prox
 // (IDENT = 1 swaps the prox for the identity: plain gradient descent on the dual).
-template <int PLAIN, int IDENT, int TV_U>
+template <int NT>
+__device__ __forceinline__ void store_d2(d2* p, d2 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int NT>
+__device__ __forceinline__ void store_f64(double* p, double v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int NT>
+__device__ __forceinline__ double load_f64(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <int PLAIN, int IDENT, int TV_U, int NT>
 __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -59,21 +67,26 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
   const uint32_t i0 = rc * p.rows_wg;
   const uint32_t rows = min(p.rows_wg, p.H - i0);
-  const uint32_t c = (sg * 4u + wave) * TV_SW + lane;     // image column this lane loads
-  const bool own = lane < TV_SW && c < p.W;               // lane 63 (and columns past W) only feed neighbours
-  const uint32_t cl = c % p.W;                            // periodic wrap for the halo column
+  const uint32_t first = (sg * 4u + wave) * TV_SW;
+  const uint32_t c = first + lane;                        // image column of this lane
+  const bool own = c < p.W;
+  const uint32_t cl = own ? c : c % p.W;                  // columns past W wrap: they act as right neighbours
+  const uint32_t hc = (first + TV_SW) % p.W;              // halo column right of the strip (for lane 63)
   double v[5] = {0, 0, 0, 0, 0};                          // dxg0, dx2, xh2, g02, rdot
   double fs = 0.0;
 
-  // prox'd pixel of image row `row` in this lane's column, from raw loads; owner side effects when `mine`
-  auto finish = [&](d2 x0v, d2 g0v, uint64_t pix, bool mine) -> d2 {
-    if (PLAIN) return x0v;
-    d2 xh;
+  auto prox_of = [&](d2 x0v, d2 g0v, d2& xh) -> d2 {
+    if (PLAIN) { xh = x0v; return x0v; }
     xh.x = fwd_point(x0v.x, g0v.x, p.tau);
     xh.y = fwd_point(x0v.y, g0v.y, p.tau);
-    const d2 xp = IDENT ? xh : tv_ball(xh);
-    if (mine) {
-      reinterpret_cast<d2*>(p.xp)[pix] = xp;
+    return IDENT ? xh : tv_ball(xh);
+  };
+  // prox'd pixel from raw loads; owner side effects (store + reductions) when `mine`
+  auto finish = [&](d2 x0v, d2 g0v, uint64_t pix, bool mine) -> d2 {
+    d2 xh;
+    const d2 xp = prox_of(x0v, g0v, xh);
+    if (!PLAIN && mine) {
+      store_d2<NT>(reinterpret_cast<d2*>(p.xp) + pix, xp);
       d2 xav = {0.0, 0.0};
       if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
 #pragma unroll
@@ -93,9 +106,9 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   d2 cur;
   {
     const uint64_t pix = (uint64_t)i0 * p.W + cl;
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[pix];
+    const d2 x0v = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
     d2 g0v = {0.0, 0.0};
-    if (!PLAIN) g0v = reinterpret_cast<const d2*>(p.g0)[pix];
+    if (!PLAIN) g0v = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + pix);
     cur = finish(x0v, g0v, pix, own);
   }
   for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
@@ -107,17 +120,30 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
       const uint32_t rr = min(r0 + u + 1u, rows);                 // row below output row r0+u (clamped past the chunk)
       uint32_t nrow = i0 + rr; if (nrow >= p.H) nrow -= p.H;      // periodic
       npix[u] = (uint64_t)nrow * p.W + cl;
-      xv[u] = reinterpret_cast<const d2*>(p.x0)[npix[u]];
+      xv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + npix[u]);
       gv[u] = (d2){0.0, 0.0};
-      if (!PLAIN) gv[u] = reinterpret_cast<const d2*>(p.g0)[npix[u]];
+      if (!PLAIN) gv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + npix[u]);
       const uint32_t orow = min(i0 + r0 + u, p.H - 1u);
-      bv[u] = (p.sub_b && own) ? p.b[(uint64_t)orow * p.W + c] : 0.0;
+      bv[u] = (p.sub_b && own) ? load_f64<NT>(p.b + (uint64_t)orow * p.W + c) : 0.0;
+    }
+    // halo: lane u (< TV_U) fetches and prox's the pixel right of the strip in output row r0+u
+    double halo_y = 0.0;
+    if (lane < (uint32_t)TV_U) {
+      const uint32_t orow = min(i0 + r0 + lane, p.H - 1u);
+      const uint64_t hp = (uint64_t)orow * p.W + hc;
+      const d2 hx = reinterpret_cast<const d2*>(p.x0)[hp];
+      d2 hg = {0.0, 0.0};
+      if (!PLAIN) hg = reinterpret_cast<const d2*>(p.g0)[hp];
+      d2 hh;
+      halo_y = prox_of(hx, hg, hh).y;
     }
 #pragma unroll
     for (int u = 0; u < TV_U; ++u) {
       if (r0 + u < rows) {                                        // wave-uniform
         const d2 nxt = finish(xv[u], gv[u], npix[u], own && (r0 + u + 1u < rows));
-        const double right_y = __shfl_down(cur.y, 1, 64);        // pixel (row, col+1), component 1
+        double right_y = __shfl_down(cur.y, 1, 64);               // pixel (row, col+1), component 1
+        const double edge_y = __shfl(halo_y, u, 64);
+        if (lane == 63u) right_y = edge_y;
         double zv;
         {
 #pragma clang fp contract(off)
@@ -126,7 +152,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
           zv = t0 + t1;
         }
         if (own) {
-          p.z[(uint64_t)(i0 + r0 + u) * p.W + c] = zv;
+          store_f64<NT>(p.z + (uint64_t)(i0 + r0 + u) * p.W + c, zv);
           const double rv = p.sub_b ? sub_nofma(zv, bv[u]) : zv;
           fs = fma(rv, rv, fs);
         }
@@ -163,7 +189,7 @@ struct TvAdjP {
   double* out;
 };
 
-template <int TV_U>
+template <int TV_U, int NT>
 __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -171,18 +197,18 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
   const uint32_t i0 = rc * p.rows_wg;
   const uint32_t rows = min(p.rows_wg, p.H - i0);
-  // lane 0 is the left halo: column (first owned column - 1), periodic
   const uint32_t first = (sg * 4u + wave) * TV_SW;
-  const uint32_t c = first + lane - 1u;                    // wraps to 0xFFFFFFFF for first == 0, lane == 0
-  const bool own = lane >= 1u && c < p.W;
-  const uint32_t cl = (lane == 0u) ? (first == 0u ? p.W - 1u : (first - 1u) % p.W) : c % p.W;
+  const uint32_t c = first + lane;
+  const bool own = c < p.W;
+  const uint32_t cl = own ? c : c % p.W;
+  const uint32_t hc = (first == 0u) ? p.W - 1u : (first - 1u) % p.W;     // halo column left of the strip (for lane 0)
   double v[5] = {0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax
   double fs = 0.0;
 
   auto resid = [&](uint64_t pix) -> double {
-    double zv = p.z[pix];
+    double zv = load_f64<NT>(p.z + pix);
     if (p.accel) zv = extrapolate(zv, p.zacc0[pix], p.coef);
-    return p.sub_b ? sub_nofma(zv, p.b[pix]) : zv;
+    return p.sub_b ? sub_nofma(zv, load_f64<NT>(p.b + pix)) : zv;
   };
 
   double up;
@@ -198,25 +224,32 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
       const uint32_t row = min(i0 + r0 + u, p.H - 1u);
       const uint64_t pix = (uint64_t)row * p.W + cl;
       me[u] = resid(pix);
+      x0v[u] = g0v[u] = xpv[u] = xav[u] = (d2){0.0, 0.0};
       if (p.mode == 0) {
-        x0v[u] = reinterpret_cast<const d2*>(p.x0)[pix];
-        g0v[u] = reinterpret_cast<const d2*>(p.g0)[pix];
-        xpv[u] = reinterpret_cast<const d2*>(p.xp)[pix];
-        xav[u] = (d2){0.0, 0.0};
+        x0v[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
+        g0v[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + pix);
+        xpv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.xp) + pix);
         if (p.accel) xav[u] = reinterpret_cast<const d2*>(p.xacc0)[pix];
       }
+    }
+    double halo_r = 0.0;                                          // lane u: residual left of the strip in row r0+u
+    if (lane < (uint32_t)TV_U) {
+      const uint32_t row = min(i0 + r0 + lane, p.H - 1u);
+      halo_r = resid((uint64_t)row * p.W + hc);
     }
 #pragma unroll
     for (int u = 0; u < TV_U; ++u) {
       if (r0 + u < rows) {                                       // wave-uniform
-        const double left = __shfl_up(me[u], 1, 64);             // residual at (row, col-1)
+        double left = __shfl_up(me[u], 1, 64);                   // residual at (row, col-1)
+        const double edge = __shfl(halo_r, u, 64);
+        if (lane == 0u) left = edge;
         d2 g;
         g.x = sub_nofma(up, me[u]);                              // roll(X, +1, axis 0) - X
         g.y = sub_nofma(left, me[u]);                            // roll(X, +1, axis 1) - X
         if (own) {
           const uint64_t pix = (uint64_t)(i0 + r0 + u) * p.W + c;
           fs = fma(me[u], me[u], fs);
-          reinterpret_cast<d2*>(p.g1)[pix] = g;
+          store_d2<NT>(reinterpret_cast<d2*>(p.g1) + pix, g);
           if (p.mode == 0) {
             d2 x1v;
 #pragma unroll

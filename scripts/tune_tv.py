@@ -29,8 +29,10 @@ def timed(kid, fn, reps=5):
     return ms / cnt
 
 
-for u in (2, 4, 8):
-    for rows in (16, 32, 64, 128, 256):
+import itertools
+for nt, u, rows in itertools.product((1, 0), (2, 4, 8), (16, 32, 64, 128)):
+    if True:
+        ctx.set_tuning(hip.TUNE_NT_LOADS, nt)
         ctx.set_tuning(hip.TUNE_TV_U, u)
         ctx.set_tuning(hip.TUNE_TV_ROWS, rows)
         out = []
@@ -41,5 +43,5 @@ for u in (2, 4, 8):
             ta = timed(hip.K_ADJ, lambda: ctx.adj(0.1))
             out.append(f"{name}: fwd {tf:6.3f} ms {64 * P / tf / 1e6:6.0f} GB/s | adj {ta:6.3f} ms "
                        f"{80 * P / ta / 1e6:6.0f} GB/s(80P) {72 * P / ta / 1e6:6.0f}(72P)")
-        print(f"U={u} rows={rows:3d}  " + "  ||  ".join(out), flush=True)
+        print(f"nt={nt} U={u} rows={rows:3d}  " + "  ||  ".join(out), flush=True)
 A.close()
