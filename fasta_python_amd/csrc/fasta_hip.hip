@@ -133,8 +133,8 @@ struct fh_ctx {
   int adj_cpt = 0;           // 0 = auto
   int ld_pad = 0;
   int nt_loads = 1;
-  int tv_u = 4;
-  int tv_rows = 64;
+  int tv_u = 8;              // measured best on MI355X at 8192^2 (profiles/r01_tune_tv.txt)
+  int tv_rows = 16;
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
