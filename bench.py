@@ -181,6 +181,8 @@ def run_tv(args, grp):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
                      "avg_launch_ms": dms / dcnt, "algorithmic_bytes_per_launch": dbytes,
+                     "note": "priced at the materialised-vector model of SURVEY.md 8(d) (64*P / 72*P); this build never "
+                             "materialises the gradient and moves 56*P per launch (fh_tv.h)",
                      "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1], "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9}
                                     for k, v in per.items() if v[1]},
                      "loop_GB/s_wallclock": (fwd_cnt * 64 * P + adj_cnt * 72 * P) / elapsed / 1e9},

@@ -98,6 +98,7 @@ struct fh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int op = OP_NONE;
+  bool op_pending_stencil = false;
   uint64_t m = 0, n = 0;     // logical (local) rows / columns of A   (stencil: m = H*W, n = 2*H*W)
   uint64_t mp = 0, ld = 0;   // padded rows, device leading dimension (dense)
   uint64_t nv = 0, mv = 0;   // allocated n-side / m-side vector lengths (doubles)
@@ -116,6 +117,9 @@ struct fh_ctx {
   double* b = nullptr;
   double* Z[2] = {nullptr, nullptr};
   double* zt = nullptr;
+  double* ZX[2] = {nullptr, nullptr};   // stencil + FISTA: extrapolated z' (the residual source of the next g0)
+  int zxc = 0;
+  const double* zcur = nullptr;         // stencil: z at the current x0 (Z[zc], or ZX[zxc] after an accelerated step)
   bool has_b = false;
   // prox
   int prox_kind = FH_PROX_IDENTITY;
@@ -160,7 +164,7 @@ static void free_operator(fh_ctx* c) {
   auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   fr(c->A);
   for (int i = 0; i < 2; ++i) { fr(c->X[i]); fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
-  fr(c->xhat); fr(c->best); fr(c->b); fr(c->zt);
+  fr(c->xhat); fr(c->best); fr(c->b); fr(c->zt); fr(c->ZX[0]); fr(c->ZX[1]);
   for (int i = 0; i < 4; ++i) fr(c->T[i]);
   fr(c->ws); c->ws_bytes = 0;
   c->op = OP_NONE; c->has_b = false;
@@ -185,7 +189,9 @@ static int alloc_vectors(fh_ctx* c) {
   for (int i = 0; i < 4; ++i) FH_TRY(alloc_zero(c, &c->T[i], c->nv + 16));
   FH_TRY(alloc_zero(c, &c->b, c->mv + 16));
   FH_TRY(alloc_zero(c, &c->zt, c->mv + 16));
-  c->xc = c->pc = c->gc = c->zc = 0;
+  if (c->op_pending_stencil) { FH_TRY(alloc_zero(c, &c->ZX[0], c->mv + 16)); FH_TRY(alloc_zero(c, &c->ZX[1], c->mv + 16)); }
+  c->xc = c->pc = c->gc = c->zc = c->zxc = 0;
+  c->zcur = nullptr;
   return 0;
 }
 
@@ -375,7 +381,9 @@ extern "C" int fh_set_stencil(fh_ctx* c, uint64_t H, uint64_t W) {
   c->m = H * W; c->n = 2 * H * W;
   c->mp = c->m; c->ld = c->n;
   c->nv = round_up(c->n, 16); c->mv = round_up(c->m, 16);
+  c->op_pending_stencil = true;
   FH_TRY(alloc_vectors(c));
+  c->op_pending_stencil = false;
   c->op = OP_STENCIL;
   return finish(c);
 }
@@ -409,6 +417,8 @@ extern "C" int fh_set_prox(fh_ctx* c, int kind, double mu, double lo, double hi)
 static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
   const bool acc = c->last_accel;
   *len = c->n;
+  // the stencil path never materialises the gradient or xhat (fh_tv.h): those ids are not addressable there
+  if (c->op == OP_STENCIL && (which == FH_VEC_G0 || which == FH_VEC_G1 || which == FH_VEC_XHAT)) return nullptr;
   switch (which) {
     case FH_VEC_X0: return c->X[c->xc];
     case FH_VEC_G0: return c->G[c->gc];
@@ -618,52 +628,86 @@ static int launch_level_search(fh_ctx* c, double tau) {
 
 static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                          double* xhat, double* xp, double* z, int sub_b) {
-  (void)xhat;   // the stencil path never materialises xhat: K-adj recomputes x0 - tau*g0 bit-identically
+  (void)xhat; (void)g0;   // the stencil path materialises neither xhat nor the gradient (fh_tv.h)
   if (mode == 0 && c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
     return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
+  const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
+  const uint32_t rows_wg = (uint32_t)c->tv_rows;
+  const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
+  if (mode == 0) {
+    if (!c->zcur) return fail(FH_E_STATE, "fh_fwd on the stencil operator before fh_init");
+    TvStepFwdP p;
+    p.H = H; p.W = W; p.rows_wg = rows_wg;
+    p.strip_groups = ((W + TVS_FWD_OWN - 1) / TVS_FWD_OWN + 3) / 4;
+    p.x0 = x0; p.xacc0 = xacc0; p.xp = xp; p.zc = c->zcur; p.b = c->b; p.zn = z; p.tau = tau;
+    const unsigned grid = p.strip_groups * row_chunks;
+    FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
+    p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
+    t_begin(c, FH_K_FWD);
+#define TV_STEP(U, NT)                                                                                           \
+  do {                                                                                                           \
+    if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
+    else k_fwd_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
+  } while (0)
+    if (c->nt_loads) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
+    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
+#undef TV_STEP
+    t_end(c, FH_K_FWD);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   TvFwdP p;
-  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  const uint32_t strips = (p.W + TV_SW - 1) / TV_SW;
-  p.strip_groups = (strips + 3) / 4;
-  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xp = xp; p.b = c->b; p.z = z;
+  p.H = H; p.W = W; p.rows_wg = rows_wg;
+  p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
+  p.x0 = x0; p.g0 = nullptr; p.xacc0 = nullptr; p.xp = xp; p.b = c->b; p.z = z;
   p.tau = tau; p.sub_b = sub_b;
-  p.rows_wg = (uint32_t)c->tv_rows;
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
-#define TV_FWD(U, NT)                                                                                          \
-  do {                                                                                                         \
-    if (mode != 0) k_fwd_tv<1, 0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                        \
-    else if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv<0, 0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p); \
-    else k_fwd_tv<0, 1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
-  } while (0)
-  if (c->nt_loads) { if (c->tv_u == 2) TV_FWD(2, 1); else if (c->tv_u == 8) TV_FWD(8, 1); else TV_FWD(4, 1); }
-  else { if (c->tv_u == 2) TV_FWD(2, 0); else if (c->tv_u == 8) TV_FWD(8, 0); else TV_FWD(4, 0); }
-#undef TV_FWD
+  if (c->nt_loads) k_fwd_tv<1, 0, 4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fwd_tv<1, 0, 4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
-  TvAdjP p;
-  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  const uint32_t strips = (p.W + TV_SW - 1) / TV_SW;
-  p.strip_groups = (strips + 3) / 4;
-  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.accel = io.accel; p.coef = io.coef;
-  p.mode = io.mode; p.tau = io.tau;
-  p.x0 = io.x0; p.g0 = io.g0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.g1 = io.g1;
-  if (p.mode == 0 && !p.g0) return fail(FH_E_STATE, "stencil adjoint epilogue needs g0");
-  p.rows_wg = (uint32_t)c->tv_rows;
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
+  const uint32_t rows_wg = (uint32_t)c->tv_rows;
+  const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
+  if (io.mode == 0) {          // FBS step: reductions only, the gradient is recomputed from z and b
+    if (!c->zcur) return fail(FH_E_STATE, "fh_adj on the stencil operator before fh_init");
+    TvStepAdjP p;
+    p.H = H; p.W = W; p.rows_wg = rows_wg;
+    p.strip_groups = ((W + TVS_ADJ_OWN - 1) / TVS_ADJ_OWN + 3) / 4;
+    p.zn = io.z; p.zacc0 = io.zacc0; p.zc = c->zcur; p.b = c->b;
+    p.accel = io.accel; p.coef = io.coef; p.tau = io.tau;
+    p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.zx = c->ZX[c->zxc ^ 1];
+    const unsigned grid = p.strip_groups * row_chunks;
+    FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
+    p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
+    t_begin(c, FH_K_ADJ);
+#define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
+    if (c->nt_loads) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
+    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
+#undef TV_STEP
+    t_end(c, FH_K_ADJ);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  TvAdjP p;                    // plain gradient (Lipschitz probes, fh_apply): materialises g1 = grad(z - b)
+  p.H = H; p.W = W; p.rows_wg = rows_wg;
+  p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
+  p.z = io.z; p.zacc0 = nullptr; p.b = c->b; p.sub_b = io.sub_b; p.accel = 0; p.coef = 0.0;
+  p.mode = 1; p.tau = io.tau;
+  p.x0 = nullptr; p.g0 = nullptr; p.xp = nullptr; p.xacc0 = nullptr; p.x1 = nullptr; p.g1 = io.g1;
+  const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
   t_begin(c, FH_K_ADJ);
-#define TV_ADJ(U, NT) k_adj_tv<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-  if (c->nt_loads) { if (c->tv_u == 2) TV_ADJ(2, 1); else if (c->tv_u == 8) TV_ADJ(8, 1); else TV_ADJ(4, 1); }
-  else { if (c->tv_u == 2) TV_ADJ(2, 0); else if (c->tv_u == 8) TV_ADJ(8, 0); else TV_ADJ(4, 0); }
-#undef TV_ADJ
+  if (c->nt_loads) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_adj_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_ADJ);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -713,8 +757,12 @@ extern "C" int fh_init(fh_ctx* c, double* scalars) {
   // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
   FH_TRY(op_fwd(c, 1, 0.0, x0, nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
-  AdjIO io = {c->Z[c->zc], nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->G[c->gc]};
-  FH_TRY(op_adj(c, io));
+  if (c->op == OP_STENCIL) {
+    c->zcur = c->Z[c->zc];       // g0 = grad(zcur - b) is recomputed inside the step kernels
+  } else {
+    AdjIO io = {c->Z[c->zc], nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->G[c->gc]};
+    FH_TRY(op_adj(c, io));
+  }
   // x_accel1 := x0, best := x0 ; g(x0) terms for objective_hist[0] (:143) come from the host wrapper via FH_VEC ops
   HIP_TRY(hipMemcpyAsync(c->P[c->pc], x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->best, x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -783,6 +831,10 @@ extern "C" int fh_commit(fh_ctx* c, int save_best) {
   }
   c->zc ^= 1;     // z_accel0 <- z1
   c->gc ^= 1;     // g0 <- g1
+  if (c->op == OP_STENCIL) {
+    if (c->last_accel) { c->zxc ^= 1; c->zcur = c->ZX[c->zxc]; }   // residual source = extrapolated z'
+    else c->zcur = c->Z[c->zc];                                      // residual source = z1 itself
+  }
   if (save_best)
     HIP_TRY(hipMemcpyAsync(c->best, c->X[c->xc], c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;

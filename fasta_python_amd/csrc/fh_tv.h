@@ -12,11 +12,9 @@
 // neighbour is the previous row's value kept in a register; the horizontal neighbour comes from the
 // adjacent lane by __shfl, and for the strip's edge lane from a halo pixel that lanes 0..TV_U-1 fetch
 // (one lane per row of the batch) and broadcast.  Loads are issued TV_U rows ahead.
-//   K-fwd: xhat = y0 - tau*g0, xprox = xhat / max(||xhat||_2, 1) per pixel (tv_denoising.py:89-96),
-//          z = div(xprox), ||z-b||^2 and the line-search reductions.  xhat is NOT written (K-adj
-//          recomputes it from y0, g0 bit-identically).  HBM bytes: reads 16+16+8, writes 16+8 = 64*P.
-//   K-adj: r = z' - b, g1 = grad(r), Dg / BB reductions (+ FISTA extrapolation).
-//          HBM bytes: reads 8+8 (z,b) + 16*3 (y0,g0,xprox), writes 16 = 80*P  (SURVEY model: 72*P).
+// The first pair below (k_fwd_tv / k_adj_tv) is the PLAIN pair: z = div(x0) and g = grad(z - b) with
+// materialised outputs -- used by fh_init, fh_apply and the Lipschitz probes.  The FBS-step pair
+// (k_fwd_tv_step / k_adj_tv_step, end of this file) never materialises the gradient.
 #pragma once
 #include "fh_device.h"
 
@@ -271,6 +269,250 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
           }
         }
         up = me[u];
+      }
+    }
+  }
+  double w[6] = {v[0], v[1], v[2], v[3], v[4], fs};
+  block_reduce<6>(w, s_scr, 4);
+  if (!publish_partials<6>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
+  double t[6] = {0, 0, 0, 0, 0, 0};
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double q = load_partial(p.red + (uint64_t)i * 8 + k);
+      if (k == 4) t[k] = fmax(t[k], q); else t[k] += q;
+    }
+  }
+  block_reduce<6>(t, s_scr, 4);
+  if (tid == 0) {
+    p.out[S_DXDG] = t[0]; p.out[S_DG2] = t[1]; p.out[S_XH2_ADJ] = t[2]; p.out[S_GSUM_ADJ] = t[3];
+    p.out[S_GMAX_ADJ] = t[4]; p.out[S_FSQ_ADJ] = t[5];
+    __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// =================================================================================================
+// FBS-step kernels that never materialise the gradient.
+//
+// For the stencil pair, g = grad(r) is a 2-point difference of the residual r = z - b, so storing g
+// (16 B/pixel written by K-adj, 16 B/pixel read by K-fwd) costs more than recomputing it from z and b
+// (8 + 8 B/pixel, and b is needed anyway).  With z_cur = A x0 (the previous launch's output):
+//   K-fwd step : g0 = grad(z_cur - b) on the fly; xhat, xprox, z_new = div(xprox), reductions.
+//                reads x0 16 + z_cur 8 + b 8, writes xprox 16 + z_new 8            = 56 B/pixel
+//   K-adj step : g1 = grad(z_new' - b), g0 again (for xhat), BB reductions only.
+//                reads z_new 8 + z_cur 8 + b 8 + x0 16 + xprox 16, writes nothing   = 56 B/pixel
+//                (+ FISTA: reads z_acc0 8 + x_acc0 16, writes z' 8 + x1 16)
+// i.e. 112*P per iteration against the materialised-vector model's 136*P; the
+// roofline line still prices the launches at the model's 64*P / 72*P.  Every value is produced by the same
+// IEEE operations as the reference (r = z - b, g = r_neighbour - r, xhat = x0 - tau*g), so parity is
+// unchanged.  Waves own overlapping strips (one halo lane per needed side) so all lanes run one code path.
+// =================================================================================================
+#define TVS_FWD_OWN 62     // lanes 1..62 own; lane 0 / 63 are the left / right halo columns
+#define TVS_ADJ_OWN 63     // lanes 1..63 own; lane 0 is the left halo column
+
+struct TvStepFwdP {
+  uint32_t H, W, strip_groups, rows_wg;
+  const double* x0; const double* xacc0;   // (H,W,2)
+  double* xp;                               // (H,W,2)
+  const double* zc; const double* b;        // (H,W): z at x0, target
+  double* zn;                               // (H,W): div(xprox)
+  double tau;
+  double* red; unsigned* counter; double* out;
+};
+
+template <int IDENT, int TV_U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_fwd_tv_step(const TvStepFwdP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
+  const uint32_t first = (sg * 4u + wave) * TVS_FWD_OWN;
+  const uint32_t c = first + lane - 1u;                      // 0xFFFFFFFF for the very first halo lane
+  const bool own = lane >= 1u && lane <= (uint32_t)TVS_FWD_OWN && c < p.W;
+  const uint32_t cl = (lane == 0u && first == 0u) ? p.W - 1u : c % p.W;
+  double v[5] = {0, 0, 0, 0, 0};                             // dxg0, dx2, xh2, g02, rdot
+  double fs = 0.0;
+
+  // forward point + prox of one pixel given its residual neighbourhood; owner side effects when `mine`
+  auto step_pixel = [&](d2 x0v, double r_me, double r_up, double r_left, uint64_t pix, bool mine) -> d2 {
+    d2 g0v, xh;
+    g0v.x = sub_nofma(r_up, r_me);                           // grad(r)[..,0] = roll(r,+1,axis 0) - r
+    g0v.y = sub_nofma(r_left, r_me);                         // grad(r)[..,1] = roll(r,+1,axis 1) - r
+    xh.x = fwd_point(x0v.x, g0v.x, p.tau);
+    xh.y = fwd_point(x0v.y, g0v.y, p.tau);
+    const d2 xp = IDENT ? xh : tv_ball(xh);
+    if (mine) {
+      store_d2<NT>(reinterpret_cast<d2*>(p.xp) + pix, xp);
+      d2 xav = {0.0, 0.0};
+      if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double dx = sub_nofma(xp[e], x0v[e]);
+        const double dh = sub_nofma(xp[e], xh[e]);
+        v[0] = fma(dx, g0v[e], v[0]);
+        v[1] = fma(dx, dx, v[1]);
+        v[2] = fma(dh, dh, v[2]);
+        v[3] = fma(g0v[e], g0v[e], v[3]);
+        v[4] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], xav[e]), v[4]);
+      }
+    }
+    return xp;
+  };
+
+  double r_up, b_cur;
+  d2 cur;
+  {
+    const uint32_t prow = (i0 == 0u) ? p.H - 1u : i0 - 1u;
+    const uint64_t ppix = (uint64_t)prow * p.W + cl;
+    r_up = sub_nofma(load_f64<NT>(p.zc + ppix), load_f64<NT>(p.b + ppix));
+    const uint64_t pix = (uint64_t)i0 * p.W + cl;
+    const d2 x0v = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
+    b_cur = load_f64<NT>(p.b + pix);
+    const double r_me = sub_nofma(load_f64<NT>(p.zc + pix), b_cur);
+    const double r_left = __shfl_up(r_me, 1, 64);
+    cur = step_pixel(x0v, r_me, r_up, r_left, pix, own);
+    r_up = r_me;
+  }
+  for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
+    d2 xv[TV_U];
+    double zv[TV_U], bv[TV_U];
+    uint64_t npix[TV_U];
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      const uint32_t rr = min(r0 + u + 1u, rows);                 // row below output row r0+u (clamped past the chunk)
+      uint32_t nrow = i0 + rr; if (nrow >= p.H) nrow -= p.H;      // periodic
+      npix[u] = (uint64_t)nrow * p.W + cl;
+      xv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + npix[u]);
+      zv[u] = load_f64<NT>(p.zc + npix[u]);
+      bv[u] = load_f64<NT>(p.b + npix[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      if (r0 + u < rows) {                                        // wave-uniform
+        const double r_n = sub_nofma(zv[u], bv[u]);
+        const double r_left = __shfl_up(r_n, 1, 64);
+        const d2 nxt = step_pixel(xv[u], r_n, r_up, r_left, npix[u], own && (r0 + u + 1u < rows));
+        const double right_y = __shfl_down(cur.y, 1, 64);         // xprox(row, col+1)[1]
+        double zo;
+        {
+#pragma clang fp contract(off)
+          const double t0 = nxt.x - cur.x;                        // roll(Y0, -1, axis 0) - Y0
+          const double t1 = right_y - cur.y;                      // roll(Y1, -1, axis 1) - Y1
+          zo = t0 + t1;
+        }
+        if (own) {
+          store_f64<NT>(p.zn + (uint64_t)(i0 + r0 + u) * p.W + c, zo);
+          const double rv = sub_nofma(zo, b_cur);
+          fs = fma(rv, rv, fs);
+        }
+        cur = nxt; b_cur = bv[u]; r_up = r_n;
+      }
+    }
+  }
+  double w[8] = {fs, v[0], v[1], v[2], v[3], 0.0, 0.0, v[4]};   // S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, -, -, S_RDOT
+  block_reduce<8>(w, s_scr, -1);
+  if (!publish_partials<8>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] += load_partial(p.red + (uint64_t)i * 8 + k);
+  }
+  block_reduce<8>(t, s_scr, -1);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.out[k] = t[k];
+    __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+struct TvStepAdjP {
+  uint32_t H, W, strip_groups, rows_wg;
+  const double* zn; const double* zacc0; const double* zc; const double* b;   // (H,W)
+  int accel; double coef; double tau;
+  const double* x0; const double* xp; const double* xacc0;                    // (H,W,2)
+  double* x1; double* zx;                                                      // FISTA outputs: x1 (H,W,2), z' (H,W)
+  double* red; unsigned* counter; double* out;
+};
+
+template <int TV_U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_adj_tv_step(const TvStepAdjP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
+  const uint32_t first = (sg * 4u + wave) * TVS_ADJ_OWN;
+  const uint32_t c = first + lane - 1u;
+  const bool own = lane >= 1u && c < p.W;
+  const uint32_t cl = (lane == 0u && first == 0u) ? p.W - 1u : c % p.W;
+  double v[5] = {0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax
+  double fs = 0.0;
+
+  auto z_new_at = [&](uint64_t pix) -> double {          // z1' of fasta/__init__.py:243 (z1 itself without FISTA)
+    double zv = load_f64<NT>(p.zn + pix);
+    if (p.accel) zv = extrapolate(zv, p.zacc0[pix], p.coef);
+    return zv;
+  };
+
+  double rn_up, rc_up;
+  {
+    const uint32_t prow = (i0 == 0u) ? p.H - 1u : i0 - 1u;
+    const uint64_t ppix = (uint64_t)prow * p.W + cl;
+    const double bp = load_f64<NT>(p.b + ppix);
+    rn_up = sub_nofma(z_new_at(ppix), bp);
+    rc_up = sub_nofma(load_f64<NT>(p.zc + ppix), bp);
+  }
+  for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
+    double zn[TV_U], zc[TV_U], bv[TV_U];
+    d2 x0v[TV_U], xpv[TV_U], xav[TV_U];
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      const uint32_t row = min(i0 + r0 + u, p.H - 1u);
+      const uint64_t pix = (uint64_t)row * p.W + cl;
+      zn[u] = z_new_at(pix);
+      zc[u] = load_f64<NT>(p.zc + pix);
+      bv[u] = load_f64<NT>(p.b + pix);
+      x0v[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
+      xpv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.xp) + pix);
+      xav[u] = (d2){0.0, 0.0};
+      if (p.accel) xav[u] = reinterpret_cast<const d2*>(p.xacc0)[pix];
+    }
+#pragma unroll
+    for (int u = 0; u < TV_U; ++u) {
+      if (r0 + u < rows) {                                       // wave-uniform
+        const double rn = sub_nofma(zn[u], bv[u]);
+        const double rcur = sub_nofma(zc[u], bv[u]);
+        const double rn_left = __shfl_up(rn, 1, 64);
+        const double rc_left = __shfl_up(rcur, 1, 64);
+        if (own) {
+          const uint64_t pix = (uint64_t)(i0 + r0 + u) * p.W + c;
+          d2 g1, g0;
+          g1.x = sub_nofma(rn_up, rn);    g1.y = sub_nofma(rn_left, rn);
+          g0.x = sub_nofma(rc_up, rcur);  g0.y = sub_nofma(rc_left, rcur);
+          fs = fma(rn, rn, fs);
+          if (p.accel) p.zx[pix] = zn[u];
+          d2 x1v;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double xh = fwd_point(x0v[u][e], g0[e], p.tau);       // same bits as K-fwd's xhat
+            double x1 = xpv[u][e];
+            if (p.accel) x1 = extrapolate(xpv[u][e], xav[u][e], p.coef);
+            const double dx = sub_nofma(xpv[u][e], x0v[u][e]);
+            const double dg = bb_dgrad(g1[e], xh, x0v[u][e], p.tau);
+            const double dh = sub_nofma(x1, xh);
+            v[0] = fma(dx, dg, v[0]);
+            v[1] = fma(dg, dg, v[1]);
+            v[2] = fma(dh, dh, v[2]);
+            v[3] += fabs(x1);
+            v[4] = fmax(v[4], fabs(x1));
+            x1v[e] = x1;
+          }
+          if (p.accel) reinterpret_cast<d2*>(p.x1)[pix] = x1v;
+        }
+        rn_up = rn; rc_up = rcur;
       }
     }
   }

@@ -101,7 +101,14 @@ def _device_prox(tag, x, t):
     if tag.kind == hip.PROX_TVBALL:
         assert x.ndim == 3 and x.shape[-1] == 2
         with _Scratch(GradDivMap(x.shape[:2])) as op:
-            return _one_prox(op.ctx, tag, flat, t).reshape(x.shape)
+            # the stencil path recomputes g0 = grad(A x0 - b); with b := A x it is exactly zero, so xhat = x
+            ctx = op.ctx
+            ctx.set_loss_lsq(ctx.apply(flat))
+            ctx.set_prox(tag.kind, tag.mu, tag.lo, tag.hi)
+            ctx.set_vector(hip.VEC_X0, flat)
+            ctx.init()
+            ctx.fwd(t)
+            return ctx.get_vector(hip.VEC_XPROX, flat.size).reshape(x.shape)
     ctx = hip.HipContext(0)
     try:
         ctx.set_matrix(np.zeros((1, flat.size)))
