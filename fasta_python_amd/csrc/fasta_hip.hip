@@ -137,8 +137,11 @@ struct fh_ctx {
   int adj_cpt = 0;           // 0 = auto
   int ld_pad = 0;
   int nt_loads = 1;
-  int tv_u = 8;              // measured best on MI355X at 8192^2 (profiles/r01_tune_tv.txt)
-  int tv_rows = 16;
+  // stencil defaults measured on MI355X at 8192^2 (profiles/r01_tune_tv.txt): plain (not nt) accesses,
+  // 8 rows in flight, 32 rows per workgroup for K-fwd and 128 for the read-only K-adj
+  int tv_u = 8;
+  int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
+  int tv_nt = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
@@ -314,8 +317,10 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       if (value != 2 && value != 4 && value != 8) return fail(FH_E_ARG, "TV_U must be 2, 4 or 8");
       c->tv_u = (int)value; return 0;
     case FH_TUNE_TV_ROWS:
-      if (value < 1 || value > 4096) return fail(FH_E_ARG, "TV_ROWS must be in [1,4096]");
+      if (value < 0 || value > 4096) return fail(FH_E_ARG, "TV_ROWS must be in [0,4096] (0 = auto)");
       c->tv_rows = (int)value; return 0;
+    case FH_TUNE_TV_NT:
+      c->tv_nt = value ? 1 : 0; return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
   }
 }
@@ -632,7 +637,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   if (mode == 0 && c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
     return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
   const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
-  const uint32_t rows_wg = (uint32_t)c->tv_rows;
+  const uint32_t rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
   const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
   if (mode == 0) {
     if (!c->zcur) return fail(FH_E_STATE, "fh_fwd on the stencil operator before fh_init");
@@ -649,7 +654,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
     if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fwd_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-    if (c->nt_loads) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
+    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
     else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
 #undef TV_STEP
     t_end(c, FH_K_FWD);
@@ -665,7 +670,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
-  if (c->nt_loads) k_fwd_tv<1, 0, 4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_nt) k_fwd_tv<1, 0, 4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_fwd_tv<1, 0, 4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
@@ -674,7 +679,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
 
 static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
-  const uint32_t rows_wg = (uint32_t)c->tv_rows;
+  const uint32_t rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 128);
   const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
   if (io.mode == 0) {          // FBS step: reductions only, the gradient is recomputed from z and b
     if (!c->zcur) return fail(FH_E_STATE, "fh_adj on the stencil operator before fh_init");
@@ -689,7 +694,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
     p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
     t_begin(c, FH_K_ADJ);
 #define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-    if (c->nt_loads) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
+    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
     else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
 #undef TV_STEP
     t_end(c, FH_K_ADJ);
@@ -706,7 +711,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
   t_begin(c, FH_K_ADJ);
-  if (c->nt_loads) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_nt) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_adj_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_ADJ);
   HIP_TRY(hipGetLastError());

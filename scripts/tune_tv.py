@@ -32,7 +32,7 @@ def timed(kid, fn, reps=5):
 import itertools
 for nt, u, rows in itertools.product((1, 0), (2, 4, 8), (16, 32, 64, 128)):
     if True:
-        ctx.set_tuning(hip.TUNE_NT_LOADS, nt)
+        ctx.set_tuning(hip.TUNE_TV_NT, nt)
         ctx.set_tuning(hip.TUNE_TV_U, u)
         ctx.set_tuning(hip.TUNE_TV_ROWS, rows)
         out = []
