@@ -57,7 +57,9 @@ class Group:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
-        if self.world > 1:
+        # FASTA_BENCH_FORCE_DIST=1 rehearses the multi-process plumbing (gloo + RCCL communicator) with one rank
+        self.force = os.environ.get("FASTA_BENCH_FORCE_DIST") == "1"
+        if self.world > 1 or self.force:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -216,7 +218,7 @@ def main():
     A = fa.DenseMatrixMap.synthetic(m_local, n, seed=0, scale=scale, row0=row0, m_total=m_total,
                                     device=grp.local_rank, tuning=tuning)
     ctx = A.ctx
-    if grp.world > 1:
+    if grp.world > 1 or grp.force:
         uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
         ctx.comm_init(grp.world, grp.rank, uid)
 
