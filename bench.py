@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--m", type=int, default=65536, help="total rows of A (default: BASELINE config 2)")
-    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--rows", dest="m", type=int, default=65536, help="total rows of A (default: BASELINE config 2)")
+    ap.add_argument("--cols", dest="n", type=int, default=65536)
     ap.add_argument("--workload", default="lasso", choices=["lasso", "nnls", "tv"],
                     help="lasso = BASELINE config 2 (default, the headline); nnls = config 3; tv = config 4 (8192^2 image)")
     ap.add_argument("--image", type=int, default=8192, help="TV image side (workload tv)")
