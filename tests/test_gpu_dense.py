@@ -237,3 +237,32 @@ def test_full_size_properties_65536():
         assert np.array_equal(op.H(e), pr.synth_matrix(1, n, 0, scale, row0=12345, n_total=n)[0])
     finally:
         op.close()
+
+
+def test_c2_full_size_first_iterations_match_oracle_loop():
+    """BASELINE config 2 at FULL size (65536^2, 32 GiB): the first iterations of the HIP solve against the
+    oracle NumPy loop on a host copy of the same device-generated matrix (BASELINE.md section 4 parity gate:
+    x rtol 1e-5, scalars rtol 1e-8, identical backtrack counts)."""
+    m = n = 65536
+    iters = 3
+    scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap.synthetic(m, n, 0, scale)
+    try:
+        x_true = pr.synth_sparse_signal(n, 1)
+        b = op(x_true) + 0.01 * np.random.RandomState(2).randn(m)
+        ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+        opts = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, record_iterates=True)
+        np.random.seed(3)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, **opts)
+        A = op.host_rows(0, m)                       # 32 GiB host copy, D2H
+    finally:
+        op.close()
+    P = pr.sparse_least_squares_from(A, b, 0.02)
+    np.random.seed(3)
+    want = fo.fasta(*P.args7(), **opts)
+    assert got.iteration_count == want.iteration_count == iters
+    assert got.backtracks == want.backtracks
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(got, f)[:iters], getattr(want, f)[:iters], rtol=1e-8, err_msg=f)
+    np.testing.assert_allclose(got.objectives[:iters + 1], want.objectives[:iters + 1], rtol=1e-8)
+    np.testing.assert_allclose(got.iterates[:iters + 1], want.iterates[:iters + 1], rtol=1e-5, atol=1e-12)
