@@ -664,14 +664,14 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   TvFwdP p;
   p.H = H; p.W = W; p.rows_wg = rows_wg;
   p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
-  p.x0 = x0; p.g0 = nullptr; p.xacc0 = nullptr; p.xp = xp; p.b = c->b; p.z = z;
-  p.tau = tau; p.sub_b = sub_b;
+  (void)xp; (void)tau;
+  p.x0 = x0; p.b = c->b; p.z = z; p.sub_b = sub_b;
   const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
   t_begin(c, FH_K_FWD);
-  if (c->tv_nt) k_fwd_tv<1, 0, 4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_fwd_tv<1, 0, 4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_nt) k_fwd_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fwd_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -704,9 +704,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   TvAdjP p;                    // plain gradient (Lipschitz probes, fh_apply): materialises g1 = grad(z - b)
   p.H = H; p.W = W; p.rows_wg = rows_wg;
   p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
-  p.z = io.z; p.zacc0 = nullptr; p.b = c->b; p.sub_b = io.sub_b; p.accel = 0; p.coef = 0.0;
-  p.mode = 1; p.tau = io.tau;
-  p.x0 = nullptr; p.g0 = nullptr; p.xp = nullptr; p.xacc0 = nullptr; p.x1 = nullptr; p.g1 = io.g1;
+  p.z = io.z; p.b = c->b; p.sub_b = io.sub_b; p.g1 = io.g1;
   const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;

@@ -21,20 +21,6 @@
 #define TV_SW 64       // owned columns per wave
 // rows per workgroup (p.rows_wg) and rows of loads in flight (template TV_U) are tunables, see fh_set_tuning
 
-struct TvFwdP {
-  uint32_t H, W;
-  uint32_t strip_groups;      // ceil(ceil(W/63)/4): 4 wave strips per workgroup
-  uint32_t rows_wg;           // rows per workgroup
-  const double* x0; const double* g0; const double* xacc0;   // (H,W,2)
-  double* xp;                                                 // (H,W,2)
-  const double* b; double* z;                                 // (H,W)
-  double tau;
-  int sub_b;
-  double* red;          // [grid][8]
-  unsigned* counter;
-  double* out;
-};
-
 // unit-ball projection of one pixel's 2-vector: Y / max(||Y||_2, 1)   (examples/tv_denoising.py:89-96)
 __device__ __forceinline__ d2 tv_ball(d2 y) {
 #pragma clang fp contract(off)
@@ -48,8 +34,6 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
   return r;
 }
 
-// PLAIN = 1: xprox := x0 (fh_init / fh_apply / Lipschitz probes); PLAIN = 0: FBS step with the TV-ball prox
-// (IDENT = 1 swaps the prox for the identity: plain gradient descent on the dual).
 template <int NT>
 __device__ __forceinline__ void store_d2(d2* p, d2 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 template <int NT>
@@ -57,7 +41,22 @@ __device__ __forceinline__ void store_f64(double* p, double v) { if (NT) __built
 template <int NT>
 __device__ __forceinline__ double load_f64(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
-template <int PLAIN, int IDENT, int TV_U, int NT>
+// ---- PLAIN pair -----------------------------------------------------------------------------------
+// z = div(x) (+ ||z - b||^2): aligned 64-column strips; lane 63's right neighbour is a halo pixel that lanes
+// 0..TV_U-1 fetch (one per row of the batch) and broadcast.
+struct TvFwdP {
+  uint32_t H, W;
+  uint32_t strip_groups;      // ceil(ceil(W/64)/4): 4 wave strips per workgroup
+  uint32_t rows_wg;           // rows per workgroup
+  const double* x0;           // (H,W,2)
+  const double* b; double* z; // (H,W)
+  int sub_b;
+  double* red;                // [grid][8]
+  unsigned* counter;
+  double* out;
+};
+
+template <int TV_U, int NT>
 __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -70,75 +69,29 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   const bool own = c < p.W;
   const uint32_t cl = own ? c : c % p.W;                  // columns past W wrap: they act as right neighbours
   const uint32_t hc = (first + TV_SW) % p.W;              // halo column right of the strip (for lane 63)
-  double v[5] = {0, 0, 0, 0, 0};                          // dxg0, dx2, xh2, g02, rdot
   double fs = 0.0;
 
-  auto prox_of = [&](d2 x0v, d2 g0v, d2& xh) -> d2 {
-    if (PLAIN) { xh = x0v; return x0v; }
-    xh.x = fwd_point(x0v.x, g0v.x, p.tau);
-    xh.y = fwd_point(x0v.y, g0v.y, p.tau);
-    return IDENT ? xh : tv_ball(xh);
-  };
-  // prox'd pixel from raw loads; owner side effects (store + reductions) when `mine`
-  auto finish = [&](d2 x0v, d2 g0v, uint64_t pix, bool mine) -> d2 {
-    d2 xh;
-    const d2 xp = prox_of(x0v, g0v, xh);
-    if (!PLAIN && mine) {
-      store_d2<NT>(reinterpret_cast<d2*>(p.xp) + pix, xp);
-      d2 xav = {0.0, 0.0};
-      if (p.xacc0) xav = reinterpret_cast<const d2*>(p.xacc0)[pix];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const double dx = sub_nofma(xp[e], x0v[e]);
-        const double dh = sub_nofma(xp[e], xh[e]);
-        v[0] = fma(dx, g0v[e], v[0]);
-        v[1] = fma(dx, dx, v[1]);
-        v[2] = fma(dh, dh, v[2]);
-        v[3] = fma(g0v[e], g0v[e], v[3]);
-        v[4] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], xav[e]), v[4]);
-      }
-    }
-    return xp;
-  };
-
-  d2 cur;
-  {
-    const uint64_t pix = (uint64_t)i0 * p.W + cl;
-    const d2 x0v = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
-    d2 g0v = {0.0, 0.0};
-    if (!PLAIN) g0v = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + pix);
-    cur = finish(x0v, g0v, pix, own);
-  }
+  d2 cur = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + (uint64_t)i0 * p.W + cl);
   for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
-    d2 xv[TV_U], gv[TV_U];
+    d2 xv[TV_U];
     double bv[TV_U];
-    uint64_t npix[TV_U];
 #pragma unroll
     for (int u = 0; u < TV_U; ++u) {
       const uint32_t rr = min(r0 + u + 1u, rows);                 // row below output row r0+u (clamped past the chunk)
       uint32_t nrow = i0 + rr; if (nrow >= p.H) nrow -= p.H;      // periodic
-      npix[u] = (uint64_t)nrow * p.W + cl;
-      xv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + npix[u]);
-      gv[u] = (d2){0.0, 0.0};
-      if (!PLAIN) gv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + npix[u]);
+      xv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + (uint64_t)nrow * p.W + cl);
       const uint32_t orow = min(i0 + r0 + u, p.H - 1u);
       bv[u] = (p.sub_b && own) ? load_f64<NT>(p.b + (uint64_t)orow * p.W + c) : 0.0;
     }
-    // halo: lane u (< TV_U) fetches and prox's the pixel right of the strip in output row r0+u
-    double halo_y = 0.0;
+    double halo_y = 0.0;                                          // lane u: pixel right of the strip in output row r0+u
     if (lane < (uint32_t)TV_U) {
       const uint32_t orow = min(i0 + r0 + lane, p.H - 1u);
-      const uint64_t hp = (uint64_t)orow * p.W + hc;
-      const d2 hx = reinterpret_cast<const d2*>(p.x0)[hp];
-      d2 hg = {0.0, 0.0};
-      if (!PLAIN) hg = reinterpret_cast<const d2*>(p.g0)[hp];
-      d2 hh;
-      halo_y = prox_of(hx, hg, hh).y;
+      halo_y = reinterpret_cast<const d2*>(p.x0)[(uint64_t)orow * p.W + hc].y;
     }
 #pragma unroll
     for (int u = 0; u < TV_U; ++u) {
       if (r0 + u < rows) {                                        // wave-uniform
-        const d2 nxt = finish(xv[u], gv[u], npix[u], own && (r0 + u + 1u < rows));
+        const d2 nxt = xv[u];
         double right_y = __shfl_down(cur.y, 1, 64);               // pixel (row, col+1), component 1
         const double edge_y = __shfl(halo_y, u, 64);
         if (lane == 63u) right_y = edge_y;
@@ -158,14 +111,11 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
       }
     }
   }
-  double w[8] = {fs, v[0], v[1], v[2], v[3], 0.0, 0.0, v[4]};   // S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, -, -, S_RDOT
+  double w[8] = {fs, 0, 0, 0, 0, 0, 0, 0};
   block_reduce<8>(w, s_scr, -1);
   if (!publish_partials<8>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
   double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] += load_partial(p.red + (uint64_t)i * 8 + k);
-  }
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) t[0] += load_partial(p.red + (uint64_t)i * 8);
   block_reduce<8>(t, s_scr, -1);
   if (tid == 0) {
 #pragma unroll
@@ -174,14 +124,14 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_tv(const TvFwdP p) {
   }
 }
 
+// g = grad(z - b) materialised (Lipschitz probes, fh_apply adjoint); lane 0's left neighbour is the broadcast halo.
 struct TvAdjP {
   uint32_t H, W;
   uint32_t strip_groups;
   uint32_t rows_wg;
-  const double* z; const double* zacc0; const double* b;
-  int sub_b; int accel; double coef; int mode; double tau;
-  const double* x0; const double* g0; const double* xp; const double* xacc0;
-  double* x1; double* g1;
+  const double* z; const double* b;
+  int sub_b;
+  double* g1;           // (H,W,2)
   double* red;          // [grid][8]
   unsigned* counter;
   double* out;
@@ -200,12 +150,10 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   const bool own = c < p.W;
   const uint32_t cl = own ? c : c % p.W;
   const uint32_t hc = (first == 0u) ? p.W - 1u : (first - 1u) % p.W;     // halo column left of the strip (for lane 0)
-  double v[5] = {0, 0, 0, 0, 0};   // dxdg, dg2, xh2, gsum, gmax
   double fs = 0.0;
 
   auto resid = [&](uint64_t pix) -> double {
-    double zv = load_f64<NT>(p.z + pix);
-    if (p.accel) zv = extrapolate(zv, p.zacc0[pix], p.coef);
+    const double zv = load_f64<NT>(p.z + pix);
     return p.sub_b ? sub_nofma(zv, load_f64<NT>(p.b + pix)) : zv;
   };
 
@@ -216,19 +164,10 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
   }
   for (uint32_t r0 = 0; r0 < rows; r0 += TV_U) {
     double me[TV_U];
-    d2 x0v[TV_U], g0v[TV_U], xpv[TV_U], xav[TV_U];
 #pragma unroll
     for (int u = 0; u < TV_U; ++u) {
       const uint32_t row = min(i0 + r0 + u, p.H - 1u);
-      const uint64_t pix = (uint64_t)row * p.W + cl;
-      me[u] = resid(pix);
-      x0v[u] = g0v[u] = xpv[u] = xav[u] = (d2){0.0, 0.0};
-      if (p.mode == 0) {
-        x0v[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
-        g0v[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.g0) + pix);
-        xpv[u] = load_stream<NT>(reinterpret_cast<const d2*>(p.xp) + pix);
-        if (p.accel) xav[u] = reinterpret_cast<const d2*>(p.xacc0)[pix];
-      }
+      me[u] = resid((uint64_t)row * p.W + cl);
     }
     double halo_r = 0.0;                                          // lane u: residual left of the strip in row r0+u
     if (lane < (uint32_t)TV_U) {
@@ -245,48 +184,22 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv(const TvAdjP p) {
         g.x = sub_nofma(up, me[u]);                              // roll(X, +1, axis 0) - X
         g.y = sub_nofma(left, me[u]);                            // roll(X, +1, axis 1) - X
         if (own) {
-          const uint64_t pix = (uint64_t)(i0 + r0 + u) * p.W + c;
           fs = fma(me[u], me[u], fs);
-          store_d2<NT>(reinterpret_cast<d2*>(p.g1) + pix, g);
-          if (p.mode == 0) {
-            d2 x1v;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const double xh = fwd_point(x0v[u][e], g0v[u][e], p.tau);   // same bits as K-fwd's xhat
-              double x1 = xpv[u][e];
-              if (p.accel) x1 = extrapolate(xpv[u][e], xav[u][e], p.coef);
-              const double dx = sub_nofma(xpv[u][e], x0v[u][e]);
-              const double dg = bb_dgrad(g[e], xh, x0v[u][e], p.tau);
-              const double dh = sub_nofma(x1, xh);
-              v[0] = fma(dx, dg, v[0]);
-              v[1] = fma(dg, dg, v[1]);
-              v[2] = fma(dh, dh, v[2]);
-              v[3] += fabs(x1);
-              v[4] = fmax(v[4], fabs(x1));
-              x1v[e] = x1;
-            }
-            if (p.accel) reinterpret_cast<d2*>(p.x1)[pix] = x1v;
-          }
+          store_d2<NT>(reinterpret_cast<d2*>(p.g1) + (uint64_t)(i0 + r0 + u) * p.W + c, g);
         }
         up = me[u];
       }
     }
   }
-  double w[6] = {v[0], v[1], v[2], v[3], v[4], fs};
+  double w[6] = {0, 0, 0, 0, 0, fs};
   block_reduce<6>(w, s_scr, 4);
   if (!publish_partials<6>(p.red + (uint64_t)blockIdx.x * 8, w, p.counter, gridDim.x, s_flag)) return;
   double t[6] = {0, 0, 0, 0, 0, 0};
-  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double q = load_partial(p.red + (uint64_t)i * 8 + k);
-      if (k == 4) t[k] = fmax(t[k], q); else t[k] += q;
-    }
-  }
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) t[5] += load_partial(p.red + (uint64_t)i * 8 + 5);
   block_reduce<6>(t, s_scr, 4);
   if (tid == 0) {
-    p.out[S_DXDG] = t[0]; p.out[S_DG2] = t[1]; p.out[S_XH2_ADJ] = t[2]; p.out[S_GSUM_ADJ] = t[3];
-    p.out[S_GMAX_ADJ] = t[4]; p.out[S_FSQ_ADJ] = t[5];
+    p.out[S_DXDG] = 0.0; p.out[S_DG2] = 0.0; p.out[S_XH2_ADJ] = 0.0; p.out[S_GSUM_ADJ] = 0.0;
+    p.out[S_GMAX_ADJ] = 0.0; p.out[S_FSQ_ADJ] = t[5];
     __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
