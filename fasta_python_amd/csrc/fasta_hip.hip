@@ -542,10 +542,18 @@ struct AdjIO {
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
-  // auto rules from the MI355X sweep (profiles/r01_tune_dense.txt): wide column chunks (4 x 16 B per lane) and
-  // ~1024 workgroups of up to 2048 rows each were fastest at 65536^2 (6.9 TB/s); narrower chunks for small n
+  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_sizes.txt): ~1024 workgroups of up to
+  // 2048 rows; the widest column chunk (4 x 16 B per lane, fastest stream at 65536^2: 6.9 TB/s) whose
+  // finaliser -- ONE workgroup per column chunk summing nslab x chunk bytes -- stays under ~512 KiB, because
+  // that tail is serial: at 8192^2, 4 chunks x 256 slabs (4 MiB each) cost more than the streaming itself.
   int CPT = c->adj_cpt;
-  if (CPT == 0) CPT = p.ld2 >= 4096 ? 4 : (p.ld2 >= 1024 ? 2 : 1);
+  if (CPT == 0) {
+    CPT = 1;
+    for (int cand = 4; cand >= 2; cand /= 2) {
+      const uint64_t ncc_c = (p.ld2 + FH_WG * cand - 1) / (FH_WG * cand);
+      if (ncc_c * ncc_c * 32768ull >= 1024ull * p.ld2) { CPT = cand; break; }
+    }
+  }
   p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
   uint32_t slab = (uint32_t)c->adj_slab;
   if (slab == 0) {

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     if (c >= p.ld2) continue;
     const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
     d2 g = {0.0, 0.0};
-#pragma unroll 4
+#pragma unroll 16
     for (uint32_t s = 0; s < p.nslab; ++s) g += gp[(uint64_t)s * p.ld2];
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
