@@ -131,7 +131,7 @@ struct fh_ctx {
   double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
   double* hscal = nullptr;           // pinned host mirror
   // tuning
-  int fwd_rows = 8;
+  int fwd_rows = 0;          // 0 = auto
   long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
   int adj_slab = 0;          // 0 = auto
   int adj_cpt = 0;           // 0 = auto
@@ -296,7 +296,7 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
   if (!c) return fail(FH_E_ARG, "null context");
   switch (key) {
     case FH_TUNE_FWD_ROWS:
-      if (value != 4 && value != 8 && value != 16) return fail(FH_E_ARG, "FWD_ROWS must be 4, 8 or 16");
+      if (value != 0 && value != 4 && value != 8 && value != 16) return fail(FH_E_ARG, "FWD_ROWS must be 0 (auto), 4, 8 or 16");
       c->fwd_rows = (int)value; return 0;
     case FH_TUNE_FWD_GRID_CAP:
       if (value < 0) return fail(FH_E_ARG, "FWD_GRID_CAP must be >= 0");
@@ -497,7 +497,8 @@ static void launch_fwd_r(fh_ctx* c, const FwdP& p, unsigned grid, int kind) {
 // z := A * (mode 0: prox(x0 - tau g0) ; mode 1: x0) on the dense operator
 static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                             double* xhat, double* xp, double* z, int sub_b) {
-  const int R = c->fwd_rows;
+  // rows per pass: 16 when rows are short (<= 64 KiB) and there are still >= 512 row groups, else 8 (sweep)
+  const int R = c->fwd_rows ? c->fwd_rows : ((c->ld <= 8192 && c->mp / 16 >= 512) ? 16 : 8);
   if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
   FwdP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n;
@@ -542,22 +543,16 @@ struct AdjIO {
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
-  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_sizes.txt): ~1024 workgroups of up to
-  // 2048 rows; the widest column chunk (4 x 16 B per lane, fastest stream at 65536^2: 6.9 TB/s) whose
-  // finaliser -- ONE workgroup per column chunk summing nslab x chunk bytes -- stays under ~512 KiB, because
-  // that tail is serial: at 8192^2, 4 chunks x 256 slabs (4 MiB each) cost more than the streaming itself.
+  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): column chunks of
+  // 1 / 2 / 4 x 16 B per lane for n <= 8192 / < 65536 / larger, and about one workgroup per CU (256) with
+  // slabs of 32..2048 rows.  Few fat workgroups keep the serial tail small: the finaliser of a column chunk is
+  // ONE workgroup summing nslab x chunk bytes.
   int CPT = c->adj_cpt;
-  if (CPT == 0) {
-    CPT = 1;
-    for (int cand = 4; cand >= 2; cand /= 2) {
-      const uint64_t ncc_c = (p.ld2 + FH_WG * cand - 1) / (FH_WG * cand);
-      if (ncc_c * ncc_c * 32768ull >= 1024ull * p.ld2) { CPT = cand; break; }
-    }
-  }
+  if (CPT == 0) CPT = p.ld2 <= 4096 ? 1 : (p.ld2 < 32768 ? 2 : 4);
   p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
   uint32_t slab = (uint32_t)c->adj_slab;
   if (slab == 0) {
-    const uint64_t target_slabs = std::max<uint64_t>(1, 1024 / p.ncc);
+    const uint64_t target_slabs = std::max<uint64_t>(1, 256 / p.ncc);
     uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
     slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, 32), ADJ_MAX_SLAB);
   }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
       block_reduce<7>(v, s_scr, 5);
       if (tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) p.red_n[(uint64_t)chunk * 8 + 1 + k] = v[k];
+        for (int k = 0; k < 7; ++k) store_partial(p.red_n + (uint64_t)chunk * 8 + 1 + k, v[k]);
       }
     }
   }
@@ -156,18 +156,18 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
   {
     double v[1] = {fpart};
     block_reduce<1>(v, s_scr, -1);
-    if (tid == 0) p.red_m[blockIdx.x] = v[0];
+    if (tid == 0) store_partial(p.red_m + blockIdx.x, v[0]);
   }
 
   // ---------------- last workgroup: ordered final sums ------------------------------------------
   if (arrive_last(p.counter, gridDim.x, s_flag)) {
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = tid; i < gridDim.x; i += FH_WG) v[0] += p.red_m[i];
+    for (uint32_t i = tid; i < gridDim.x; i += FH_WG) v[0] += load_partial(p.red_m + i);
     if (KIND != PX_PLAIN) {
       for (uint32_t i = tid; i < p.nchunks; i += FH_WG) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) {
-          const double t = p.red_n[(uint64_t)i * 8 + k];
+          const double t = load_partial(p.red_n + (uint64_t)i * 8 + k);
           if (k == S_GMAX) v[k] = fmax(v[k], t); else v[k] += t;
         }
       }
@@ -275,12 +275,12 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
     const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
-    if (c < p.ld2) reinterpret_cast<d2*>(p.gpart)[(uint64_t)slab * p.ld2 + c] = acc[j];
+    if (c < p.ld2) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)slab * p.ld2 + c, acc[j]);
   }
   if (cc == 0) {
     double v[1] = {fs};
     block_reduce<1>(v, s_scr, -1);
-    if (tid == 0) p.red_f[slab] = v[0];
+    if (tid == 0) store_partial(p.red_f + slab, v[0]);
   }
 
   // ---- last workgroup of this column chunk: ordered slab sum + n-side epilogue ---------------------
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
     d2 g = {0.0, 0.0};
 #pragma unroll 16
-    for (uint32_t s = 0; s < p.nslab; ++s) g += gp[(uint64_t)s * p.ld2];
+    for (uint32_t s = 0; s < p.nslab; ++s) g += load_partial2(gp + (uint64_t)s * p.ld2);
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
       const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   block_reduce<5>(v, s_scr, 4);
   if (tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) p.red_bb[(uint64_t)cc * 8 + k] = v[k];
+    for (int k = 0; k < 5; ++k) store_partial(p.red_bb + (uint64_t)cc * 8 + k, v[k]);
   }
 
   // ---- last column-chunk finaliser: ordered scalar sums ------------------------------------------
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   for (uint32_t i = tid; i < p.ncc; i += FH_WG) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      const double t = p.red_bb[(uint64_t)i * 8 + k];
+      const double t = load_partial(p.red_bb + (uint64_t)i * 8 + k);
       if (k == 4) w[k] = fmax(w[k], t); else w[k] += t;
     }
   }
-  for (uint32_t i = tid; i < p.nslab; i += FH_WG) w[5] += p.red_f[i];
+  for (uint32_t i = tid; i < p.nslab; i += FH_WG) w[5] += load_partial(p.red_f + i);
   block_reduce<6>(w, s_scr, 4);
   if (tid == 0) {
     p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
@@ -357,14 +357,14 @@ __global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p, uint32_t nc
   block_reduce<5>(v, s_scr, 4);
   if (tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) p.red_bb[(uint64_t)blockIdx.x * 8 + k] = v[k];
+    for (int k = 0; k < 5; ++k) store_partial(p.red_bb + (uint64_t)blockIdx.x * 8 + k, v[k]);
   }
   if (!arrive_last(p.fin_counter, nchunks, s_flag)) return;
   double w[5] = {0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < nchunks; i += FH_WG) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-      const double t = p.red_bb[(uint64_t)i * 8 + k];
+      const double t = load_partial(p.red_bb + (uint64_t)i * 8 + k);
       if (k == 4) w[k] = fmax(w[k], t); else w[k] += t;
     }
   }
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(FH_WG) void k_diff_sq(const double* a, const double
     v[0] = fma(d, d, v[0]);
   }
   block_reduce<1>(v, s_scr, -1);
-  if (threadIdx.x == 0) red[blockIdx.x] = v[0];
+  if (threadIdx.x == 0) store_partial(red + blockIdx.x, v[0]);
   if (!arrive_last(counter, gridDim.x, s_flag)) return;
   double w[1] = {0.0};
-  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) w[0] += red[i];
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) w[0] += load_partial(red + i);
   block_reduce<1>(w, s_scr, -1);
   if (threadIdx.x == 0) {
     out[0] = w[0];
@@ -426,10 +426,10 @@ __global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len,
     v[1] = fmax(v[1], a);
   }
   block_reduce<2>(v, s_scr, 1);
-  if (threadIdx.x == 0) { red[2 * blockIdx.x] = v[0]; red[2 * blockIdx.x + 1] = v[1]; }
+  if (threadIdx.x == 0) { store_partial(red + 2 * blockIdx.x, v[0]); store_partial(red + 2 * blockIdx.x + 1, v[1]); }
   if (!arrive_last(counter, gridDim.x, s_flag)) return;
   double w[2] = {0.0, 0.0};
-  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) { w[0] += red[2 * i]; w[1] = fmax(w[1], red[2 * i + 1]); }
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += FH_WG) { w[0] += load_partial(red + 2 * i); w[1] = fmax(w[1], load_partial(red + 2 * i + 1)); }
   block_reduce<2>(w, s_scr, 1);
   if (threadIdx.x == 0) {
     out[S_GSUM] = w[0]; out[S_GMAX] = w[1];

@@ -5,11 +5,9 @@
 //   * Elementwise solver arithmetic (forward step, prox, BB terms) is written with FMA contraction
 //     OFF so each operation rounds exactly like the NumPy expression it replaces
 //     (fasta/__init__.py:181, :242, :254); dot products and matvec accumulations use explicit fma().
-//   * Cross-workgroup hand-offs (partials -> last-arriving workgroup) follow the agent-scope
-//     release / acquire recipe of the CDNA4 guide (Guideline 16): every storing wave drains vmcnt,
-//     workgroup barrier, lane 0 release-fences and bumps an agent-scope counter; the workgroup whose
-//     add came last acquire-fences before any wave reads the partials.  All reductions are summed in
-//     index order, never arrival order, so results are bitwise repeatable run to run.
+//   * Cross-workgroup hand-offs (partials -> last-arriving workgroup) use write-through `sc1` atomic
+//     stores/loads + an agent-scope ticket (CDNA4 guide, Guideline 16); see arrive_last below.  All
+//     reductions are summed in index order, never arrival order, so results are bitwise repeatable.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -107,47 +105,54 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* scr, int ma
   __syncthreads();
 }
 
-// Producer side of a "last workgroup finishes" hand-off; returns true in EVERY thread of the
-// workgroup whose arrival was the `total`-th.  `flag` is one LDS word owned by the caller.
-__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, volatile unsigned* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // keep the write-back ahead of the ticket
-    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned last = (t == total - 1u) ? 1u : 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  return *flag != 0u;
+// ---- cross-workgroup hand-off of partial results ("last workgroup to arrive finishes the reduction") ------
+// Fence-free form of the CDNA4 guide (Guideline 16, visibility table row 1): EVERY byte that is handed off
+// is stored write-through by an agent-scope relaxed atomic store (`global_store_dwordx2 sc1`), every storing
+// wave drains `vmcnt`, the workgroup barriers, ONE lane takes a ticket with an agent-scope atomic add; the
+// workgroup whose add came last is the consumer and reads every handed-off byte with agent-scope relaxed
+// atomic loads (`sc1`, served past this CU's L1).  No `buffer_wbl2` / `buffer_inv`, so the kernels' bulk
+// outputs are neither flushed nor waited for.  Partials are always combined in index order => repeatable.
+__device__ __forceinline__ void store_partial(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// Light hand-off for REDUCTION PARTIALS ONLY (K doubles per workgroup, all held by thread 0):
-// the partials go out as agent-scope relaxed atomic stores (write-through `sc1`), thread 0 drains them and
-// takes the ticket; the last workgroup reads them back with agent-scope relaxed atomic loads (`sc1`, served
-// past this CU's L1).  No release fence => no `buffer_wbl2` of the whole XCD L2, which matters in kernels
-// that dirty megabytes of their own output (the stencil kernels): their bulk stores are not part of the
-// hand-off and must not be flushed or waited for.  (CDNA4 guide, Guideline 16 / visibility table row 1.)
-template <int K>
-__device__ __forceinline__ bool publish_partials(double* slot, const double (&v)[K], unsigned* counter, unsigned total,
-                                                 volatile unsigned* flag) {
+__device__ __forceinline__ double load_partial(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_partial2(d2* p, d2 v) {
+  store_partial(reinterpret_cast<double*>(p), v.x);
+  store_partial(reinterpret_cast<double*>(p) + 1, v.y);
+}
+__device__ __forceinline__ d2 load_partial2(const d2* p) {
+  d2 v;
+  v.x = load_partial(reinterpret_cast<const double*>(p));
+  v.y = load_partial(reinterpret_cast<const double*>(p) + 1);
+  return v;
+}
+// all waves may have stored partials: returns true in EVERY thread of the last-arriving workgroup
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, volatile unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+  __syncthreads();
   if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) __hip_atomic_store(slot + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = (t == total - 1u) ? 1u : 0u;
   }
   __syncthreads();
   return *flag != 0u;
 }
-__device__ __forceinline__ double load_partial(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+// K doubles per workgroup, all held by thread 0 (the usual case after block_reduce)
+template <int K>
+__device__ __forceinline__ bool publish_partials(double* slot, const double (&v)[K], unsigned* counter, unsigned total,
+                                                 volatile unsigned* flag) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) store_partial(slot + k, v[k]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == total - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag != 0u;
 }
 
 // 16-byte streaming load of A.  NT=1 marks it non-temporal (read-once stream; keeps x0/g0 in L2).

@@ -79,7 +79,7 @@ enum fh_scalar {
 enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_NKERNELS = 4 };
 
 enum fh_tuning_key {
-  FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8 or 16                */
+  FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8, 16 (0 = auto)        */
   FH_TUNE_FWD_GRID_CAP = 1,  /* max workgroups of K-fwd (0 = auto: 1024, grid-stride over row groups) */
   FH_TUNE_ADJ_SLAB_ROWS = 2, /* rows per K-adj slab (multiple of 8; 0 = auto)               */
   FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */

@@ -16,7 +16,7 @@ def time_kernel(ctx, kid, fn, reps=10):
     return ms / cnt
 
 
-for m, n in ((2048, 2048), (4096, 4096), (8192, 8192), (16384, 16384), (512, 1024), (16384, 2048), (2048, 16384)):
+for m, n in ((2048, 2048), (4096, 4096), (8192, 8192), (16384, 16384), (512, 1024), (16384, 2048), (2048, 16384), (32768, 32768), (65536, 65536)):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)
@@ -37,11 +37,11 @@ for m, n in ((2048, 2048), (4096, 4096), (8192, 8192), (16384, 16384), (512, 102
     best = ", ".join(f"cpt={c} slab={s}: {t * 1e3:.1f}us" for t, c, s in res[:5])
     print(f"{m}x{n}: auto {auto * 1e3:.1f}us ({m * n * 8 / auto / 1e6:.0f} GB/s) | best: {best}", flush=True)
     fres = []
-    for rows, cap in itertools.product((4, 8, 16), (0, 256, 512, 1024, 2048)):
+    for rows, cap in itertools.product((4, 8, 16), (0, 256, 512, 768, 1024, 2048)):
         ctx.set_tuning(hip.TUNE_FWD_ROWS, rows); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, cap if cap else 1 << 30)
         t = time_kernel(ctx, hip.K_FWD, lambda: ctx.fwd(0.2))
         fres.append((t, rows, cap))
-    ctx.set_tuning(hip.TUNE_FWD_ROWS, 8); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, 0)
+    ctx.set_tuning(hip.TUNE_FWD_ROWS, 0); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, 0)
     autof = time_kernel(ctx, hip.K_FWD, lambda: ctx.fwd(0.2))
     fres.sort()
     bestf = ", ".join(f"rows={r} cap={c}: {t * 1e3:.1f}us" for t, r, c in fres[:4])

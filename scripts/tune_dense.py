@@ -48,7 +48,7 @@ for pad in [int(p) for p in args.pads.split(",")]:
         ctx.set_tuning(hip.TUNE_FWD_ROWS, r); ctx.set_tuning(hip.TUNE_NT_LOADS, nt); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, cap)
         t = time_kernel(ctx, hip.K_FWD, lambda: ctx.fwd(tau), args.reps)
         print(f"fwd pad={pad:3d} rows={r:2d} nt={nt} cap={cap:5d}: {t:8.3f} ms  {mat_bytes / t / 1e6:7.0f} GB/s", flush=True)
-    ctx.set_tuning(hip.TUNE_FWD_ROWS, 8); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, 0)
+    ctx.set_tuning(hip.TUNE_FWD_ROWS, 0); ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, 0)
     slabs = (128, 256, 512, 1024, 2048) if not args.quick else (512, 1024)
     for cpt, slab, nt in itertools.product((1, 2, 4), slabs, (1, 0)):
         ctx.set_tuning(hip.TUNE_ADJ_CPT, cpt); ctx.set_tuning(hip.TUNE_ADJ_SLAB_ROWS, slab); ctx.set_tuning(hip.TUNE_NT_LOADS, nt)
