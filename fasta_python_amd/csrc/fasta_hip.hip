@@ -497,8 +497,8 @@ static void launch_fwd_r(fh_ctx* c, const FwdP& p, unsigned grid, int kind) {
 // z := A * (mode 0: prox(x0 - tau g0) ; mode 1: x0) on the dense operator
 static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                             double* xhat, double* xp, double* z, int sub_b) {
-  // rows per pass: 16 when rows are short (<= 64 KiB) and there are still >= 512 row groups, else 8 (sweep)
-  const int R = c->fwd_rows ? c->fwd_rows : ((c->ld <= 8192 && c->mp / 16 >= 512) ? 16 : 8);
+  // rows per pass (sweep, profiles/r01_tune_sizes.txt): 4 up to n = 32768, 8 beyond
+  const int R = c->fwd_rows ? c->fwd_rows : (c->ld <= 32768 ? 4 : 8);
   if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
   FwdP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n;
@@ -509,9 +509,9 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   p.px = make_prox(c, tau);
   const int kind = mode == 0 ? c->prox_kind : (int)PX_PLAIN;
   unsigned grid = std::max(p.nrg, mode == 0 ? p.nchunks : 1u);
-  // measured on MI355X at 65536^2 (profiles/r01_tune_dense.txt): ~4 persistent workgroups per CU beat one
-  // workgroup per row group by 5-12 %
-  grid = (unsigned)std::min<long long>(grid, c->fwd_cap > 0 ? c->fwd_cap : 1024);
+  // measured on MI355X (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): 2 persistent workgroups per CU
+  // grid-striding over the row groups beat one workgroup per row group by 5-12 %
+  grid = (unsigned)std::min<long long>(grid, c->fwd_cap > 0 ? c->fwd_cap : 512);
   const size_t need = ((size_t)p.nchunks * 8 + grid) * sizeof(double);
   FH_TRY(ensure_ws(c, need));
   p.red_n = c->ws; p.red_m = c->ws + (size_t)p.nchunks * 8;
@@ -543,18 +543,18 @@ struct AdjIO {
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
-  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): column chunks of
-  // 1 / 2 / 4 x 16 B per lane for n <= 8192 / < 65536 / larger, and about one workgroup per CU (256) with
-  // slabs of 32..2048 rows.  Few fat workgroups keep the serial tail small: the finaliser of a column chunk is
-  // ONE workgroup summing nslab x chunk bytes.
+  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): about 32 slabs
+  // (more when there are few column chunks, so that >= 128 workgroups exist), slabs of 32..2048 rows, and
+  // column chunks of 2 x 16 B per lane below n = 32768, 4 x 16 B from there on (1 x for n <= 1024).
   int CPT = c->adj_cpt;
-  if (CPT == 0) CPT = p.ld2 <= 4096 ? 1 : (p.ld2 < 32768 ? 2 : 4);
+  if (CPT == 0) CPT = p.ld2 <= 512 ? 1 : (p.ld2 < 16384 ? 2 : 4);
   p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
   uint32_t slab = (uint32_t)c->adj_slab;
   if (slab == 0) {
-    const uint64_t target_slabs = std::max<uint64_t>(1, 256 / p.ncc);
+    const uint64_t target_slabs = std::max<uint64_t>(32, (128 + p.ncc - 1) / p.ncc);
+    const uint64_t slab_min = p.ncc >= 8 ? 128 : 32;
     uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
-    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, 32), ADJ_MAX_SLAB);
+    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, slab_min), ADJ_MAX_SLAB);
   }
   p.slab_rows = slab;
   p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
