@@ -129,7 +129,8 @@ struct fh_ctx {
   size_t ws_bytes = 0;
   unsigned* counters = nullptr;      // 4096 words, zeroed at creation; kernels leave them zero
   double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
-  double* hscal = nullptr;           // pinned host mirror
+  double* hscal = nullptr;           // pinned, device-mapped host block: single-GPU launches write their scalars here
+  double* hscal_dev = nullptr;       // device-side address of hscal
   // tuning
   int fwd_rows = 0;          // 0 = auto
   long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
@@ -230,8 +231,13 @@ static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending e
   return 0;
 }
 
+// Where kernels write the FH_S_* block: straight into the mapped host block on one GPU (no D2H copy, the
+// stream sync alone publishes it); device memory when row-sharded, because RCCL reduces scalars in place.
+static inline double* scalar_out(fh_ctx* c) { return c->comm ? c->dscal : c->hscal_dev; }
+
 static int fetch_scalars(fh_ctx* c, double* scalars) {
-  HIP_TRY(hipMemcpyAsync(c->hscal, c->dscal, FH_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (c->comm)
+    HIP_TRY(hipMemcpyAsync(c->hscal, c->dscal, FH_NSCALARS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   FH_TRY(finish(c));
   if (scalars) memcpy(scalars, c->hscal, FH_NSCALARS * sizeof(double));
   return 0;
@@ -254,12 +260,16 @@ extern "C" int fh_create(int device, fh_ctx** out) {
   fh_ctx* c = new fh_ctx();
   c->device = device;
   HIP_TRY(hipSetDevice(device));
+  (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // spin on stream syncs: the host waits ~2x per iteration
+  (void)hipGetLastError();
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
   HIP_TRY(hipMalloc((void**)&c->dscal, (FH_NSCALARS + 16) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->dscal, 0, (FH_NSCALARS + 16) * sizeof(double), c->stream));
-  HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocMapped));
+  memset(c->hscal, 0, (FH_NSCALARS + 16) * sizeof(double));
+  HIP_TRY(hipHostGetDevicePointer((void**)&c->hscal_dev, c->hscal, 0));
   for (int k = 0; k < FH_NKERNELS; ++k) {
     HIP_TRY(hipEventCreate(&c->ev[k][0]));
     HIP_TRY(hipEventCreate(&c->ev[k][1]));
@@ -516,7 +526,7 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   FH_TRY(ensure_ws(c, need));
   p.red_n = c->ws; p.red_m = c->ws + (size_t)p.nchunks * 8;
   p.counter = c->counters + CNT_FWD;
-  p.out = c->dscal;
+  p.out = scalar_out(c);
   t_begin(c, FH_K_FWD);
   switch (R) {
     case 4: launch_fwd_r<4>(c, p, grid, kind); break;
@@ -567,7 +577,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   FH_TRY(ensure_ws(c, need));
   p.gpart = c->ws; p.red_bb = c->ws + gpart_elems; p.red_f = p.red_bb + (size_t)p.ncc * 8;
   p.cc_counter = c->counters + CNT_ADJ_CC; p.fin_counter = c->counters + CNT_ADJ_FIN;
-  p.out = c->dscal;
+  p.out = scalar_out(c);
   const unsigned grid = p.ncc * p.nslab;
   t_begin(c, FH_K_ADJ);
   switch (CPT) {
@@ -596,7 +606,7 @@ static int allreduce_and_epilogue(fh_ctx* c, const AdjIO& io) {
   p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
   const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
   FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
-  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
+  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = scalar_out(c);
   t_begin(c, FH_K_AUX);
   k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, c->dscal + FH_S_FSQ_ADJ);
   t_end(c, FH_K_AUX);
@@ -609,7 +619,7 @@ static int launch_gterms(fh_ctx* c, const double* x) {
   const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 1024);
   FH_TRY(ensure_ws(c, (size_t)grid * 2 * sizeof(double)));
   t_begin(c, FH_K_AUX);
-  k_gterms<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(x, (uint32_t)c->n, c->ws, c->counters + CNT_AUX, c->dscal);
+  k_gterms<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(x, (uint32_t)c->n, c->ws, c->counters + CNT_AUX, scalar_out(c));
   t_end(c, FH_K_AUX);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -650,7 +660,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
     p.x0 = x0; p.xacc0 = xacc0; p.xp = xp; p.zc = c->zcur; p.b = c->b; p.zn = z; p.tau = tau;
     const unsigned grid = p.strip_groups * row_chunks;
     FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-    p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
+    p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
     t_begin(c, FH_K_FWD);
 #define TV_STEP(U, NT)                                                                                           \
   do {                                                                                                           \
@@ -671,7 +681,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   p.x0 = x0; p.b = c->b; p.z = z; p.sub_b = sub_b;
   const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = c->dscal;
+  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   t_begin(c, FH_K_FWD);
   if (c->tv_nt) k_fwd_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_fwd_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
@@ -694,7 +704,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
     p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.zx = c->ZX[c->zxc ^ 1];
     const unsigned grid = p.strip_groups * row_chunks;
     FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-    p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
+    p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
     t_begin(c, FH_K_ADJ);
 #define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
     if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
@@ -710,7 +720,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   p.z = io.z; p.b = c->b; p.sub_b = io.sub_b; p.g1 = io.g1;
   const unsigned grid = p.strip_groups * row_chunks;
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = c->dscal;
+  p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
   t_begin(c, FH_K_ADJ);
   if (c->tv_nt) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_adj_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
