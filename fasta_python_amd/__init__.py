@@ -13,10 +13,10 @@ built `libfasta_hip.so` and a gfx950 GPU, and raises otherwise.
 
 from . import hip, linalg, losses, proximal, stopping
 from .linalg import DenseMatrixMap, GradDivMap, LinearMap, LinearOperator
-from .losses import LeastSquares
+from .losses import LeastSquares, LogisticLoss
 from .proximal import Box, L1Ball, LinfProx, NonNeg, NoProx, Shrink, TVDualBall
 from .solver import EPSILON, Convergence, FBSolver, fasta
 
 __all__ = ["fasta", "Convergence", "FBSolver", "EPSILON", "linalg", "proximal", "stopping", "losses", "hip",
-           "LinearMap", "LinearOperator", "DenseMatrixMap", "GradDivMap", "LeastSquares",
+           "LinearMap", "LinearOperator", "DenseMatrixMap", "GradDivMap", "LeastSquares", "LogisticLoss",
            "Shrink", "NonNeg", "LinfProx", "L1Ball", "Box", "TVDualBall", "NoProx"]

@@ -121,6 +121,7 @@ struct fh_ctx {
   int zxc = 0;
   const double* zcur = nullptr;         // stencil: z at the current x0 (Z[zc], or ZX[zxc] after an accelerated step)
   bool has_b = false;
+  int loss_kind = LOSS_LSQ;
   // prox
   int prox_kind = FH_PROX_IDENTITY;
   double mu = 0.0, lo = 0.0, hi = 0.0;
@@ -410,14 +411,24 @@ extern "C" int fh_shape(fh_ctx* c, uint64_t* m, uint64_t* n) {
   return 0;
 }
 
-extern "C" int fh_set_loss_lsq(fh_ctx* c, const double* b, uint64_t len) {
+static int set_loss(fh_ctx* c, int kind, const double* b, uint64_t len) {
   if (!c || !b) return fail(FH_E_ARG, "null argument");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "set the operator before the loss");
   if (len != c->m) return fail(FH_E_ARG, "b has %llu entries, operator has %llu rows", (unsigned long long)len, (unsigned long long)c->m);
+  if (kind != LOSS_LSQ && c->op != OP_DENSE) return fail(FH_E_STATE, "the logistic loss is implemented for the dense operator");
   FH_TRY(use_device(c));
   HIP_TRY(hipMemcpyAsync(c->b, b, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
   c->has_b = true;
+  c->loss_kind = kind;
   return finish(c);
+}
+
+extern "C" int fh_set_loss_lsq(fh_ctx* c, const double* b, uint64_t len) { return set_loss(c, LOSS_LSQ, b, len); }
+
+extern "C" int fh_set_loss_logistic(fh_ctx* c, const double* labels, uint64_t len) {
+  if (labels) for (uint64_t i = 0; i < len; ++i)
+    if (labels[i] != 1.0 && labels[i] != -1.0) return fail(FH_E_ARG, "logistic labels must be -1 or +1 (entry %llu is %g)", (unsigned long long)i, labels[i]);
+  return set_loss(c, LOSS_LOGISTIC, labels, len);
 }
 
 extern "C" int fh_set_prox(fh_ctx* c, int kind, double mu, double lo, double hi) {
@@ -515,7 +526,7 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   p.nrg = (uint32_t)(c->mp / R);
   p.nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
   p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp;
-  p.b = c->b; p.z = z; p.tau = tau; p.sub_b = sub_b;
+  p.b = c->b; p.z = z; p.tau = tau; p.sub_b = sub_b; p.loss = c->loss_kind;
   p.px = make_prox(c, tau);
   const int kind = mode == 0 ? c->prox_kind : (int)PX_PLAIN;
   unsigned grid = std::max(p.nrg, mode == 0 ? p.nchunks : 1u);
@@ -569,7 +580,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   p.slab_rows = slab;
   p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
   if (p.ncc + CNT_ADJ_CC > (uint32_t)kCounterWords) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
-  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.accel = io.accel; p.coef = io.coef;
+  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.loss = c->loss_kind; p.accel = io.accel; p.coef = io.coef;
   p.mode = io.mode; p.tau = io.tau;
   p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
   const size_t gpart_elems = (size_t)p.nslab * c->ld;

@@ -34,6 +34,7 @@ struct FwdP {
   const double* b; double* z;
   double tau;
   int sub_b;            // residual r = z - b (1) or r = z (0, fh_apply)
+  int loss;             // LOSS_LSQ / LOSS_LOGISTIC
   ProxP px;
   double* red_n;        // [nchunks][8]
   double* red_m;        // [gridDim.x]
@@ -148,8 +149,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
       const double zv = ((s_scr[tid] + s_scr[16 + tid]) + s_scr[32 + tid]) + s_scr[48 + tid];
       const uint32_t row = rg * R + tid;
       p.z[row] = zv;
-      const double rv = p.sub_b ? sub_nofma(zv, p.b[row]) : zv;
-      fpart = fma(rv, rv, fpart);
+      fpart += p.sub_b ? loss_term(zv, p.b[row], p.loss) : zv * zv;
     }
     __syncthreads();
   }
@@ -192,7 +192,8 @@ struct AdjP {
   uint32_t slab_rows;   // rows per slab (multiple of 8, <= ADJ_MAX_SLAB)
   uint32_t nslab, ncc;
   const double* z; const double* zacc0; const double* b;
-  int sub_b;            // r = z - b, else r = z
+  int sub_b;            // r = grad f(z) (z - b for least squares), else r = z
+  int loss;             // LOSS_LSQ / LOSS_LOGISTIC
   int accel;            // extrapolate z and x with `coef`
   double coef;
   int mode;             // 0 = FBS (BB epilogue), 1 = plain gradient (g1 only), 2 = sharded (g1 partial + local fsq only)
@@ -246,9 +247,9 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   for (uint32_t i = tid; i < rows; i += FH_WG) {
     double zv = p.z[row0 + i];
     if (p.accel) zv = extrapolate(zv, p.zacc0[row0 + i], p.coef);
-    const double rv = p.sub_b ? sub_nofma(zv, p.b[row0 + i]) : zv;
+    const double rv = p.sub_b ? loss_grad(zv, p.b[row0 + i], p.loss) : zv;
     s_r[i] = rv;
-    fs = fma(rv, rv, fs);
+    fs += p.sub_b ? loss_term(zv, p.b[row0 + i], p.loss) : zv * zv;
   }
   __syncthreads();
 

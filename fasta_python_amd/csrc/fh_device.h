@@ -105,6 +105,25 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* scr, int ma
   __syncthreads();
 }
 
+// ---- smooth term on the m-side: per-row value and derivative ----------------------------------------------
+// LOSS_LSQ      f = .5*sum (z-b)^2 (the kernels return sum (z-b)^2), grad = z - b   (examples/sparse_least_squares.py:41-42)
+// LOSS_LOGISTIC f = sum log(1+exp(z)) - (b==1)*z,  grad = -b / (1 + exp(b*z)),  b in {-1,+1}
+//               (examples/sparse_logistic.py:47-48).  exp/log are the device libm: last-ulp differences from NumPy.
+enum { LOSS_LSQ = 0, LOSS_LOGISTIC = 1 };
+
+__device__ __forceinline__ double loss_grad(double z, double b, int kind) {
+#pragma clang fp contract(off)
+  if (kind == LOSS_LOGISTIC) return -b / (1.0 + exp(b * z));
+  return z - b;
+}
+// contribution of one row to the scalar the host turns into f (sum of squares for LSQ, the loss itself otherwise)
+__device__ __forceinline__ double loss_term(double z, double b, int kind) {
+#pragma clang fp contract(off)
+  if (kind == LOSS_LOGISTIC) return log(1.0 + exp(z)) - (b == 1.0 ? z : 0.0);
+  const double r = z - b;
+  return r * r;
+}
+
 // ---- cross-workgroup hand-off of partial results ("last workgroup to arrive finishes the reduction") ------
 // Fence-free form of the CDNA4 guide (Guideline 16, visibility table row 1): EVERY byte that is handed off
 // is stored write-through by an agent-scope relaxed atomic store (`global_store_dwordx2 sc1`), every storing

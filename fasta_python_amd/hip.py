@@ -42,6 +42,7 @@ SIGNATURES = {
     "fh_set_stencil": (_i32, [_ctx, _u64, _u64]),
     "fh_shape": (_i32, [_ctx, C.POINTER(_u64), C.POINTER(_u64)]),
     "fh_set_loss_lsq": (_i32, [_ctx, _pd, _u64]),
+    "fh_set_loss_logistic": (_i32, [_ctx, _pd, _u64]),
     "fh_set_prox": (_i32, [_ctx, _i32, _dbl, _dbl, _dbl]),
     "fh_set_vector": (_i32, [_ctx, _i32, _pd, _u64]),
     "fh_get_vector": (_i32, [_ctx, _i32, _pd, _u64]),
@@ -172,6 +173,10 @@ class HipContext:
     def set_loss_lsq(self, b):
         b, p = _as_f64(np.ravel(b))
         self._call("fh_set_loss_lsq", p, b.size)
+
+    def set_loss_logistic(self, labels):
+        labels, p = _as_f64(np.ravel(labels))
+        self._call("fh_set_loss_logistic", p, labels.size)
 
     def set_prox(self, kind, mu=0.0, lo=0.0, hi=0.0):
         self._call("fh_set_prox", int(kind), float(mu), float(lo), float(hi))

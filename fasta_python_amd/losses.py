@@ -1,18 +1,26 @@
 """Smooth terms f(z) recognised by the device loop.
 
-LeastSquares(b):  f(z) = .5*||z - b||^2,  gradf(z) = z - b   (examples/sparse_least_squares.py:41-42,
+LogisticLoss(b): see the class.  LeastSquares(b):  f(z) = .5*||z - b||^2,  gradf(z) = z - b   (examples/sparse_least_squares.py:41-42,
 same closures in lasso.py:42-43, nn_least_squares.py:39-40, tv_denoising.py:85-86 with b = M/mu).
 Pass `ls.f` and `ls.gradf` as the `f` / `gradf` arguments of `fasta()`.
 """
 
 import numpy as np
 
-__all__ = ["LeastSquares"]
+__all__ = ["LeastSquares", "LogisticLoss"]
 
 
 class LeastSquares:
     def __init__(self, b):
         self.b = np.ascontiguousarray(b, dtype=np.float64)
+
+    def bind(self, ctx):
+        ctx.set_loss_lsq(self.b)
+
+    @staticmethod
+    def f_from_device(s):
+        """f1 from the device scalar sum (z-b)^2: .5*la.norm(z-b)**2 (sparse_least_squares.py:41)."""
+        return .5 * np.sqrt(np.float64(s)) ** 2
 
     # The device loop evaluates f inside K-fwd/K-adj; these host forms exist so the object can be
     # inspected or handed to other code.  They are never called by fasta().
@@ -22,5 +30,29 @@ class LeastSquares:
 
     def gradf(self, z):
         return np.asarray(z, dtype=np.float64) - self.b
+
+    __call__ = f
+
+
+class LogisticLoss:
+    """f(z) = sum log(1+exp(z)) - (b==1)*z, gradf(z) = -b/(1+exp(b*z)) with labels b in {-1,+1}
+    (examples/sparse_logistic.py:47-48).  Dense operators only."""
+
+    def __init__(self, b):
+        self.b = np.ascontiguousarray(b, dtype=np.float64)
+
+    def bind(self, ctx):
+        ctx.set_loss_logistic(self.b)
+
+    @staticmethod
+    def f_from_device(s):
+        return np.float64(s)
+
+    def f(self, z):
+        z = np.asarray(z, dtype=np.float64)
+        return float(np.sum(np.log(1 + np.exp(z)) - (self.b == 1) * z))
+
+    def gradf(self, z):
+        return -self.b / (1 + np.exp(self.b * np.asarray(z, dtype=np.float64)))
 
     __call__ = f

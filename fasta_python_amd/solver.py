@@ -21,7 +21,7 @@ import numpy as np
 
 from . import hip, stopping
 from .linalg import DenseMatrixMap, GradDivMap, LinearMap, _DeviceMap
-from .losses import LeastSquares
+from .losses import LeastSquares, LogisticLoss
 from .proximal import NoProx, ProxTag
 
 __all__ = ["fasta", "Convergence", "FBSolver", "EPSILON"]
@@ -67,9 +67,10 @@ def _recognise(A, At, f, gradf, g, proxg, x0):
             "fasta(): operator A is not device-resident.  Pass a 2-D float64 ndarray, a "
             "linalg.DenseMatrixMap / LinearMap.from_matrix(A), or a linalg.GradDivMap.  Arbitrary Python "
             "callables cannot run inside the fused HIP kernels and this build has no CPU fallback.")
-    loss_f, loss_g = _tag_of(f, LeastSquares), _tag_of(gradf, LeastSquares)
+    loss_f, loss_g = _tag_of(f, (LeastSquares, LogisticLoss)), _tag_of(gradf, (LeastSquares, LogisticLoss))
     if loss_f is None or loss_f is not loss_g:
-        raise TypeError("fasta(): f and gradf must be the `.f` / `.gradf` of one losses.LeastSquares(b) object")
+        raise TypeError("fasta(): f and gradf must be the `.f` / `.gradf` of one losses.LeastSquares(b) or "
+                        "losses.LogisticLoss(b) object")
     if g is None and proxg is None:
         prox = NoProx()                                                    # :88-90
     else:
@@ -83,11 +84,6 @@ def _recognise(A, At, f, gradf, g, proxg, x0):
     if loss_f.b.shape != A.Wshape:
         raise AssertionError(f"b has shape {loss_f.b.shape}, operator produces {A.Wshape}")
     return A, loss_f, prox
-
-
-def _half_sq(fsq):
-    """.5 * la.norm(r)**2 from the device's sum of squares (sparse_least_squares.py:41)."""
-    return .5 * np.sqrt(np.float64(fsq)) ** 2
 
 
 class FBSolver:
@@ -115,7 +111,9 @@ class FBSolver:
     # ------------------------------------------------------------------------------------------
     def setup(self):
         c = self.ctx
-        c.set_loss_lsq(self.loss.b)
+        self.loss.bind(c)
+        fval = self.loss.f_from_device
+        self._fval = fval
         c.set_prox(self.prox.kind, self.prox.mu, self.prox.lo, self.prox.hi)
         L, tau0 = self.L, self.tau0
         if not L or not tau0:                                           # :100-113
@@ -145,7 +143,7 @@ class FBSolver:
 
         c.set_vector(hip.VEC_X0, self.x0)
         s = c.init()                                                    # :135-137
-        f1 = _half_sq(s[hip.S_FSQ])
+        f1 = fval(s[hip.S_FSQ])
         self.f_hist[0] = f1
         self.objectives = self.iterates = self.function_hist = None
         if self.evaluate_objective:                                     # :141-143
@@ -172,8 +170,9 @@ class FBSolver:
         self.times[i] = time()                                          # :173
         tau = self.tau_next                                             # :178
 
+        fval = self._fval
         s = c.fwd(tau)                                                  # :181-188  (K-fwd)
-        f1 = _half_sq(s[hip.S_FSQ])
+        f1 = fval(s[hip.S_FSQ])
         bt = 0
         if self.backtrack:                                              # :195-217
             M = np.max(self.f_hist[max(i - self.window + 1, 0):(i + 1)])
@@ -181,7 +180,7 @@ class FBSolver:
                    and bt < self.max_backtracks):
                 tau *= self.stepsize_shrink
                 s = c.fwd(tau)                                          # :207-213  (K-fwd again)
-                f1 = _half_sq(s[hip.S_FSQ])
+                f1 = fval(s[hip.S_FSQ])
                 bt += 1
             self.total_backtracks += bt
 
@@ -197,7 +196,7 @@ class FBSolver:
 
         a = c.adj(tau, self.accelerate, coef)                           # :242-248  (K-adj)
         if self.accelerate:
-            f1 = _half_sq(a[hip.S_FSQ_ADJ])                             # :245
+            f1 = fval(a[hip.S_FSQ_ADJ])                                 # :245
             xh2, gsum, gmax = a[hip.S_XH2_ADJ], a[hip.S_GSUM_ADJ], a[hip.S_GMAX_ADJ]
         else:
             xh2, gsum, gmax = s[hip.S_XH2], s[hip.S_GSUM], s[hip.S_GMAX]

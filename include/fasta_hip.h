@@ -111,6 +111,9 @@ int fh_shape(fh_ctx* ctx, uint64_t* m, uint64_t* n);
 
 /* ---- smooth term f(z) = .5||z - b||^2, grad f(z) = z - b (examples/sparse_least_squares.py:41-42) */
 int fh_set_loss_lsq(fh_ctx* ctx, const double* b, uint64_t len);
+/* ---- smooth term f(z) = sum log(1+exp(z)) - (b==1)*z, grad f(z) = -b/(1+exp(b*z)), labels b in {-1,+1}
+ *      (examples/sparse_logistic.py:47-48); FH_S_FSQ / FH_S_FSQ_ADJ then carry f itself. Dense operator only.   */
+int fh_set_loss_logistic(fh_ctx* ctx, const double* labels, uint64_t len);
 /* ---- prox term (kinds above); mu as in the closures, lo/hi for FH_PROX_BOX only              */
 int fh_set_prox(fh_ctx* ctx, int kind, double mu, double lo, double hi);
 

@@ -41,6 +41,8 @@ def case_table():
         cases.append((f"linf_96x96_{mode}", "linf", dict(M=96, N=96, mu=0.05), 14, 104, o))
         cases.append((f"tv_32x32_{mode}", "tv", dict(H=32, W=32, square=8), 15, 105,
                       dict(o, max_iters=300)))
+        cases.append((f"logistic_100x160_{mode}", "logistic", dict(M=100, N=160, K=4, mu=4.0), 19, 106,
+                      dict(o, max_iters=400)))
     # option coverage on the sparse-LS instance
     base = dict(tolerance=1e-5)
     cases += [
@@ -80,9 +82,9 @@ def build_with_reference_ops(kind, ckw, ref):
     from oracle import problems as pr
     P = getattr(pr, {"sparse_ls": "sparse_least_squares", "nnls": "nn_least_squares",
                      "l1ball": "l1_ball_lasso", "linf": "linf_regularised",
-                     "tv": "tv_denoising"}[kind])(**ckw)
+                     "tv": "tv_denoising", "logistic": "sparse_logistic"}[kind])(**ckw)
     d = P.data
-    if kind == "sparse_ls":
+    if kind in ("sparse_ls", "logistic"):
         P.proxg = lambda x, t: ref.proximal.shrink(x, t * d["mu"])
     elif kind == "l1ball":
         P.proxg = lambda x, t: ref.proximal.project_L1_ball(x, d["mu"])

@@ -108,6 +108,25 @@ def linf_regularised_from(A, b, mu):
                    dict(A=A, b=b, mu=mu))
 
 
+def sparse_logistic(M=1000, N=2000, K=5, mu=40):
+    """examples/sparse_logistic.py:47-50 (closures), :54-80 (construct): labels b in {-1,+1}, A unnormalised."""
+    x = np.zeros(N)
+    x[np.random.permutation(N)[:K]] = 1
+    A = np.random.randn(M, N)
+    p = 1 / (1 + np.exp(-A @ x))
+    b = 2.0 * (np.random.rand(M) < p) - 1
+    return sparse_logistic_from(A, b, mu, x_true=x)
+
+
+def sparse_logistic_from(A, b, mu, x_true=None):
+    f = lambda z: np.sum(np.log(1 + np.exp(z)) - (b == 1) * z)
+    gradf = lambda z: -b / (1 + np.exp(b * z))
+    g = lambda x: mu * la.norm(x.ravel(), 1)
+    proxg = lambda x, t: fo.shrink(x, t * mu)
+    return Problem("logistic", A, A.T, f, gradf, g, proxg, np.zeros(A.shape[1]),
+                   dict(A=A, b=b, mu=mu, x_true=x_true))
+
+
 # ---- total variation (examples/tv_denoising.py) ---------------------------------------------
 def grad(X):
     """examples/tv_denoising.py:26-40: out[..., d] = roll(X, +1, axis=d) - X (periodic)."""
@@ -162,6 +181,7 @@ FROM_DATA = {
     "l1ball": lambda d: l1_ball_lasso_from(d["A"], d["b"], float(d["mu"])),
     "linf": lambda d: linf_regularised_from(d["A"], d["b"], float(d["mu"])),
     "tv": lambda d: tv_denoising_from(d["M"], float(d["mu"])),
+    "logistic": lambda d: sparse_logistic_from(d["A"], d["b"], float(d["mu"])),
 }
 
 

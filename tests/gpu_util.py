@@ -13,6 +13,7 @@ TAGS = {
     "l1ball": lambda d: fa.L1Ball(float(d["mu"])),
     "linf": lambda d: fa.LinfProx(float(d["mu"])),
     "tv": lambda d: fa.TVDualBall(),
+    "logistic": lambda d: fa.Shrink(float(d["mu"])),
 }
 
 
@@ -25,7 +26,7 @@ def hip_operands(kind, data):
         x0 = np.zeros(M.shape + (2,))
     else:
         A = fa.DenseMatrixMap(np.asarray(data["A"]))
-        loss = fa.LeastSquares(data["b"])
+        loss = fa.LogisticLoss(data["b"]) if kind == "logistic" else fa.LeastSquares(data["b"])
         x0 = np.zeros(data["A"].shape[1])
     return A, loss, TAGS[kind](data), x0
 

@@ -69,7 +69,8 @@ def test_tv_ball_prox_is_bit_exact():
 
 
 @pytest.mark.parametrize("name", ["tv_32x32_accelerated", "tv_32x32_plain", "l1ball_64x128_adaptive",
-                                  "l1ball_64x128_accelerated", "l1ball_64x128_plain"])
+                                  "l1ball_64x128_accelerated", "l1ball_64x128_plain",
+                                  "logistic_100x160_adaptive", "logistic_100x160_accelerated", "logistic_100x160_plain"])
 def test_golden_parity_full_solve(name):
     meta, z = H.load_case(name)
     data = H.case_data(meta, z)
