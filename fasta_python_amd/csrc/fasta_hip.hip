@@ -522,7 +522,7 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   const int R = c->fwd_rows ? c->fwd_rows : (c->ld <= 32768 ? 4 : 8);
   if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
   FwdP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m;
   p.nrg = (uint32_t)(c->mp / R);
   p.nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
   p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp;
@@ -563,7 +563,7 @@ struct AdjIO {
 
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp; p.m = (uint32_t)c->m;
   // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): about 32 slabs
   // (more when there are few column chunks, so that >= 128 workgroups exist), slabs of 32..2048 rows, and
   // column chunks of 2 x 16 B per lane below n = 32768, 4 x 16 B from there on (1 x for n <= 1024).

@@ -27,6 +27,7 @@ struct FwdP {
   uint64_t ld;          // doubles per device row
   uint32_t ld2;         // ld / 2  (16-byte pieces per row)
   uint32_t n;           // logical columns
+  uint32_t m;           // logical rows (padding rows carry no loss term)
   uint32_t nrg;         // row groups = mp / R
   uint32_t nchunks;     // ceil(ld2 / 256)
   const double* x0; const double* g0; const double* xacc0;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
       const double zv = ((s_scr[tid] + s_scr[16 + tid]) + s_scr[32 + tid]) + s_scr[48 + tid];
       const uint32_t row = rg * R + tid;
       p.z[row] = zv;
-      fpart += p.sub_b ? loss_term(zv, p.b[row], p.loss) : zv * zv;
+      if (row < p.m) fpart += p.sub_b ? loss_term(zv, p.b[row], p.loss) : zv * zv;
     }
     __syncthreads();
   }
@@ -189,6 +190,7 @@ struct AdjP {
   uint32_t ld2;
   uint32_t n;
   uint32_t mp;          // padded rows
+  uint32_t m;           // logical rows
   uint32_t slab_rows;   // rows per slab (multiple of 8, <= ADJ_MAX_SLAB)
   uint32_t nslab, ncc;
   const double* z; const double* zacc0; const double* b;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     if (p.accel) zv = extrapolate(zv, p.zacc0[row0 + i], p.coef);
     const double rv = p.sub_b ? loss_grad(zv, p.b[row0 + i], p.loss) : zv;
     s_r[i] = rv;
-    fs += p.sub_b ? loss_term(zv, p.b[row0 + i], p.loss) : zv * zv;
+    if (row0 + i < p.m) fs += p.sub_b ? loss_term(zv, p.b[row0 + i], p.loss) : zv * zv;
   }
   __syncthreads();
 
