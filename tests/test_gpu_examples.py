@@ -53,6 +53,7 @@ def test_config1_sparse_least_squares_through_examples_package(capsys):
     ("nn_least_squares", "NNLeastSquaresProblem", dict(M=300, N=200, seed=3)),
     ("lasso", "LASSOProblem", dict(M=100, N=300, seed=4)),
     ("tv_denoising", "TVDenoisingProblem", dict(shape=(64, 80), square=16, seed=5)),
+    ("sparse_logistic", "SparseLogisticProblem", dict(M=200, N=300, K=4, mu=8.0, seed=6)),
 ])
 def test_other_examples_run_and_converge(module, cls, kw):
     import importlib
