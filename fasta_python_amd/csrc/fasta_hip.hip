@@ -313,7 +313,7 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       if (value < 0) return fail(FH_E_ARG, "FWD_GRID_CAP must be >= 0");
       c->fwd_cap = value; return 0;
     case FH_TUNE_ADJ_SLAB_ROWS:
-      if (value < 0 || value > (1 << 20) || value % 8) return fail(FH_E_ARG, "ADJ_SLAB_ROWS must be a multiple of 8 in [0,2^20]");
+      if (value < 0 || value > ADJ_MAX_SLAB || value % 8) return fail(FH_E_ARG, "ADJ_SLAB_ROWS must be a multiple of 8 in [0,%d]", ADJ_MAX_SLAB);
       c->adj_slab = (int)value; return 0;
     case FH_TUNE_ADJ_CPT:
       if (value != 0 && value != 1 && value != 2 && value != 4) return fail(FH_E_ARG, "ADJ_CPT must be 0 (auto), 1, 2 or 4");

@@ -191,7 +191,7 @@ struct AdjP {
   uint32_t n;
   uint32_t mp;          // padded rows
   uint32_t m;           // logical rows
-  uint32_t slab_rows;   // rows per slab (multiple of 8; staged through LDS in pieces of ADJ_MAX_SLAB rows)
+  uint32_t slab_rows;   // rows per slab (multiple of 8, <= ADJ_MAX_SLAB)
   uint32_t nslab, ncc;
   const double* z; const double* zacc0; const double* b;
   int sub_b;            // r = grad f(z) (z - b for least squares), else r = z
@@ -244,6 +244,18 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   const uint32_t row0 = slab * p.slab_rows;
   const uint32_t rows = min(p.slab_rows, p.mp - row0);
 
+  // ---- stage the slab's residual r = z1' - b in LDS (z1' = extrapolated z when accelerating) ----
+  double fs = 0.0;
+  for (uint32_t i = tid; i < rows; i += FH_WG) {
+    double zv = p.z[row0 + i];
+    if (p.accel) zv = extrapolate(zv, p.zacc0[row0 + i], p.coef);
+    const double rv = p.sub_b ? loss_grad(zv, p.b[row0 + i], p.loss) : zv;
+    s_r[i] = rv;
+    if (row0 + i < p.m) fs += p.sub_b ? loss_term(zv, p.b[row0 + i], p.loss) : zv * zv;
+  }
+  __syncthreads();
+
+  // ---- stream the slab: per-column accumulators, rows walked top to bottom ------------------------
   uint32_t col[CPT];
   d2 acc[CPT];
 #pragma unroll
@@ -251,34 +263,17 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     col[j] = min(cc * (FH_WG * CPT) + j * FH_WG + tid, p.ld2 - 1u);   // clamp: redundant but in-bounds
     acc[j] = (d2){0.0, 0.0};
   }
-  double fs = 0.0;
-  // a slab may be taller than the LDS stage: walk it in pieces of ADJ_MAX_SLAB rows, accumulators stay live
-  for (uint32_t piece = 0; piece < rows; piece += ADJ_MAX_SLAB) {
-    const uint32_t prow0 = row0 + piece;
-    const uint32_t prows = min((uint32_t)ADJ_MAX_SLAB, rows - piece);
-    if (piece) __syncthreads();                       // previous piece's readers are done with s_r
-    // ---- stage the piece's residual r = grad f(z1') in LDS (z1' = extrapolated z when accelerating) ----
-    for (uint32_t i = tid; i < prows; i += FH_WG) {
-      double zv = p.z[prow0 + i];
-      if (p.accel) zv = extrapolate(zv, p.zacc0[prow0 + i], p.coef);
-      const double rv = p.sub_b ? loss_grad(zv, p.b[prow0 + i], p.loss) : zv;
-      s_r[i] = rv;
-      if (prow0 + i < p.m) fs += p.sub_b ? loss_term(zv, p.b[prow0 + i], p.loss) : zv * zv;
-    }
-    __syncthreads();
-    // ---- stream the piece: per-column accumulators, rows walked top to bottom -----------------------
-    const d2* Ab = reinterpret_cast<const d2*>(p.A) + (uint64_t)prow0 * p.ld2;
+  const d2* Ab = reinterpret_cast<const d2*>(p.A) + (uint64_t)row0 * p.ld2;
 #pragma unroll 4
-    for (uint32_t i = 0; i < prows; ++i) {
-      const double rv = s_r[i];
+  for (uint32_t i = 0; i < rows; ++i) {
+    const double rv = s_r[i];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        const d2 a = load_stream<NT>(Ab + col[j]);
-        acc[j].x = fma(a.x, rv, acc[j].x);
-        acc[j].y = fma(a.y, rv, acc[j].y);
-      }
-      Ab += p.ld2;
+    for (int j = 0; j < CPT; ++j) {
+      const d2 a = load_stream<NT>(Ab + col[j]);
+      acc[j].x = fma(a.x, rv, acc[j].x);
+      acc[j].y = fma(a.y, rv, acc[j].y);
     }
+    Ab += p.ld2;
   }
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
