@@ -1,0 +1,97 @@
+"""Randomised option/shape coverage: HIP solve vs the oracle loop on small ragged problems (every iteration,
+every mode), plus the degenerate corners of the option space the reference allows."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(A, b, kind, mu, x0, opts, seed):
+    if kind == "shrink":
+        reg, P = fa.Shrink(mu), pr.sparse_least_squares_from(A, b, mu)
+    elif kind == "nonneg":
+        reg, P = fa.NonNeg(), pr.nn_least_squares_from(A, b)
+    else:
+        reg, P = fa.L1Ball(mu), pr.l1_ball_lasso_from(A, b, mu)
+    ls = fa.LeastSquares(b)
+    np.random.seed(seed)
+    got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, **opts)
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **opts)
+    return got, want
+
+
+def _same(got, want, rtol=1e-6):
+    assert got.iteration_count == want.iteration_count
+    assert got.backtracks == want.backtracks
+    k = got.iteration_count
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(got, f)[:k], getattr(want, f)[:k], rtol=rtol, atol=1e-14, err_msg=f)
+    if want.objectives is not None:
+        np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=rtol, atol=1e-14)
+    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)
+    assert got.residuals.shape == want.residuals.shape and got.times.shape == want.times.shape     # untruncated histories
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_and_modes(seed):
+    rng = np.random.RandomState(1000 + seed)
+    m, n = int(rng.randint(1, 180)), int(rng.randint(1, 260))
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = rng.randn(m)
+    x0 = rng.randn(n) * (0.1 if seed % 2 else 0.0)                 # zero and non-zero starts
+    kind = ("shrink", "nonneg", "l1ball")[seed % 3]
+    adaptive, accelerate = [(True, False), (False, True), (False, False), (True, True)][seed % 4]
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=60, tolerance=1e-7,
+                evaluate_objective=bool(seed % 2), window=int(rng.randint(1, 12)),
+                restart=bool((seed // 2) % 2))
+    got, want = _pair(A, b, kind, 0.05, x0, opts, seed)
+    _same(got, want)
+
+
+def test_zero_iterations_returns_the_start():
+    rng = np.random.RandomState(0)
+    A, b, x0 = rng.randn(6, 9), rng.randn(6), rng.randn(9)
+    got, want = _pair(A, b, "shrink", 0.1, x0, dict(max_iters=0), 0)
+    assert got.iteration_count == want.iteration_count == 0
+    assert np.array_equal(got.solution, x0) and got.residuals.shape == (0,)
+
+
+def test_stop_at_first_iteration_and_no_backtrack_budget():
+    rng = np.random.RandomState(1)
+    A, b, x0 = rng.randn(20, 15), rng.randn(20), np.zeros(15)
+    got, want = _pair(A, b, "shrink", 0.1, x0, dict(tolerance=1e30, max_iters=5), 1)
+    assert got.iteration_count == want.iteration_count == 1
+    # unnormalised A + explicit large step: the backtracking test fires but the budget is zero (fasta/__init__.py:201)
+    got, want = _pair(A, b, "shrink", 0.1, x0, dict(L=1.0, tau0=5.0, max_backtracks=0, max_iters=4, tolerance=0.0), 1)
+    assert got.backtracks == want.backtracks == 0
+    np.testing.assert_allclose(got.residuals[:4], want.residuals[:4], rtol=1e-6)
+
+
+def test_custom_stop_rule_and_matrix_valued_iterate_shapes():
+    """stop_rule is an arbitrary host callable with the reference signature (fasta/stopping.py); x0 may be any
+    shape the operator declares (here the (H,W,2) dual variable of TV)."""
+    calls = []
+
+    def rule(i, resid, norm_resid, max_resid, tol):
+        calls.append((i, resid, norm_resid, max_resid, tol))
+        return i >= 2
+    np.random.seed(3)
+    P = pr.tv_denoising(H=12, W=10, square=4)
+    op = fa.GradDivMap((12, 10))
+    try:
+        ls, reg = fa.LeastSquares(P.data["M"] / P.data["mu"]), fa.TVDualBall()
+        np.random.seed(4)
+        c = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, stop_rule=rule, tolerance=0.5)
+    finally:
+        op.close()
+    assert c.iteration_count == 3 and [a[0] for a in calls] == [0, 1, 2] and calls[0][4] == 0.5
+    assert c.solution.shape == (12, 10, 2)
