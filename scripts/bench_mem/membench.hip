@@ -43,6 +43,41 @@ template <int NT, int WR> __global__ __launch_bounds__(256) void k_strip(const d
   if (!WR && acc.x + acc.y == 1.2345e300) d[0] = acc;
 }
 
+// TV-K-fwd-like stream mix per pixel: read 16 B + 8 B + 8 B, write 16 B + 8 B, in image strips.
+// PIX2 = 0: one pixel per lane (8-byte accesses for the scalar planes); PIX2 = 1: two pixels per lane so that
+// every access is 16 B (pixels L and L+64 of a 128-column strip for the pair planes, pixels 2L,2L+1 for the scalars).
+template <int PIX2, int NT> __global__ __launch_bounds__(256) void k_tvmix(const d2* x, const double* z, const double* b, d2* xp, double* zn,
+                                                                            uint32_t W, uint32_t rows) {
+  const uint32_t cols_per_wave = PIX2 ? 128 : 64;
+  const uint32_t groups = W / (4 * cols_per_wave);
+  const uint32_t sg = blockIdx.x % groups, rc = blockIdx.x / groups;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t c0 = (sg * 4 + wave) * cols_per_wave;
+#pragma unroll 4
+  for (uint32_t r = 0; r < rows; ++r) {
+    const uint64_t row = (uint64_t)(rc * rows + r) * W;
+    if (!PIX2) {
+      const uint64_t i = row + c0 + lane;
+      const d2 v = NT ? __builtin_nontemporal_load(x + i) : x[i];
+      const double a = NT ? __builtin_nontemporal_load(z + i) : z[i];
+      const double bb = NT ? __builtin_nontemporal_load(b + i) : b[i];
+      d2 o = v; o.x += a; o.y -= bb;
+      xp[i] = o; zn[i] = a + bb + v.x;
+    } else {
+      const uint64_t i0 = row + c0 + lane, i1 = i0 + 64;
+      const uint64_t j = (row + c0) / 2 + lane;                 // scalar planes as d2: pixels c0+2L, c0+2L+1
+      const d2 v0 = NT ? __builtin_nontemporal_load(x + i0) : x[i0];
+      const d2 v1 = NT ? __builtin_nontemporal_load(x + i1) : x[i1];
+      const d2 a = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(z) + j) : reinterpret_cast<const d2*>(z)[j];
+      const d2 bb = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2*>(b) + j) : reinterpret_cast<const d2*>(b)[j];
+      d2 o0 = v0, o1 = v1; o0.x += a.x; o1.y -= bb.y;
+      xp[i0] = o0; xp[i1] = o1;
+      d2 zo; zo.x = a.x + bb.x + v0.x; zo.y = a.y + bb.y + v1.x;
+      reinterpret_cast<d2*>(zn)[j] = zo;
+    }
+  }
+}
+
 int main() {
   const uint64_t bytes = 8ull << 30;          // 8 GiB per buffer
   const uint64_t n = bytes / 16;
@@ -75,6 +110,21 @@ int main() {
     run("strip read  nt", GB, [&] { k_strip<1, 0><<<grid, 256>>>(a, b, H, pitch, rows); });
     run("strip copy  plain (read+write)", 2 * GB, [&] { k_strip<0, 1><<<grid, 256>>>(a, b, H, pitch, rows); });
     run("strip copy  nt    (read+write)", 2 * GB, [&] { k_strip<1, 1><<<grid, 256>>>(a, b, H, pitch, rows); });
+  }
+  {
+    // TV mix on an 8192 x 8192 image: x,xp = 1 GiB each (d2 per pixel), z,b,zn = 0.5 GiB each
+    const uint32_t W = 8192, Himg = 8192;
+    const uint64_t P = (uint64_t)W * Himg;
+    d2* x = a; d2* xp = a + P;                       // inside the 8 GiB buffer a
+    double* z = (double*)b; double* bb = (double*)b + P; double* zn = (double*)b + 2 * P;
+    const double bytes56 = 56.0 * P;
+    for (uint32_t rows : {16u, 32u, 64u}) {
+      printf("--- TV-like mix (56 B/pixel), %u rows per workgroup\n", rows);
+      run("tvmix 1 px/lane plain", bytes56, [&] { k_tvmix<0, 0><<<(W / 256) * (Himg / rows), 256>>>(x, z, bb, xp, zn, W, rows); });
+      run("tvmix 1 px/lane nt-loads", bytes56, [&] { k_tvmix<0, 1><<<(W / 256) * (Himg / rows), 256>>>(x, z, bb, xp, zn, W, rows); });
+      run("tvmix 2 px/lane plain (all 16 B)", bytes56, [&] { k_tvmix<1, 0><<<(W / 512) * (Himg / rows), 256>>>(x, z, bb, xp, zn, W, rows); });
+      run("tvmix 2 px/lane nt-loads (all 16 B)", bytes56, [&] { k_tvmix<1, 1><<<(W / 512) * (Himg / rows), 256>>>(x, z, bb, xp, zn, W, rows); });
+    }
   }
   return 0;
 }
