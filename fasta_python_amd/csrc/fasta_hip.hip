@@ -14,6 +14,7 @@
 #include "fh_dense.h"
 #include "fh_tv.h"
 #include "fh_prox.h"
+#include "fh_fused.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -147,16 +148,17 @@ struct fh_ctx {
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
-  bool ev_pending[FH_NKERNELS] = {false, false, false, false};
-  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0};
-  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0};
+  bool ev_pending[FH_NKERNELS] = {false, false, false, false, false};
+  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0, 0};
+  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0, 0};
   // comm
   fh_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
+  int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
 };
 
 static const int kCounterWords = 8192;
-enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_ADJ_CC = 16 };
+enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_ADJ_CC = 16 };
 
 static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 
@@ -264,6 +266,7 @@ extern "C" int fh_create(int device, fh_ctx** out) {
   (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // spin on stream syncs: the host waits ~2x per iteration
   (void)hipGetLastError();
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); c->ncu = prop.multiProcessorCount; }
   HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
   HIP_TRY(hipMalloc((void**)&c->dscal, (FH_NSCALARS + 16) * sizeof(double)));
@@ -601,6 +604,23 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   return 0;
 }
 
+// n-side epilogue as its own launch (row-sharded runs, after the all-reduce of g1)
+static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src) {
+  AdjP p;
+  memset(&p, 0, sizeof(p));
+  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n;
+  p.accel = io.accel; p.coef = io.coef; p.mode = 0; p.tau = io.tau;
+  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
+  const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
+  FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
+  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
+  t_begin(c, FH_K_AUX);
+  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src);
+  t_end(c, FH_K_AUX);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // sharded adjoint tail: sum g1 (+ the local ||r||^2) over ranks, then the n-side epilogue
 static int allreduce_and_epilogue(fh_ctx* c, const AdjIO& io) {
   t_begin(c, FH_K_COMM);
@@ -610,19 +630,7 @@ static int allreduce_and_epilogue(fh_ctx* c, const AdjIO& io) {
   NCCL_TRY(g_rccl.GroupEnd());
   t_end(c, FH_K_COMM);
   if (io.mode != 0) return 0;
-  AdjP p;
-  memset(&p, 0, sizeof(p));
-  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n;
-  p.accel = io.accel; p.coef = io.coef; p.mode = 0; p.tau = io.tau;
-  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
-  const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
-  FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
-  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = scalar_out(c);
-  t_begin(c, FH_K_AUX);
-  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, c->dscal + FH_S_FSQ_ADJ);
-  t_end(c, FH_K_AUX);
-  HIP_TRY(hipGetLastError());
-  return 0;
+  return bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ);
 }
 
 // sum|x_i| and max|x_i| of an n-length device vector -> dscal[GSUM], dscal[GMAX]  (g(x0) for objective_hist[0], :143)
@@ -740,6 +748,65 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   return 0;
 }
 
+// ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
+static int fused_ppt(fh_ctx* c) {          // pieces per lane, or 0 when the shape is not supported
+  if (c->op != OP_DENSE || c->ncu < FT_TEAM || c->ncu % FT_TEAM) return 0;
+  if (c->prox_kind == FH_PROX_TVBALL) return 0;
+  for (int ppt = 1; ppt <= 16; ppt *= 2)
+    if (c->ld / 2 == (uint64_t)FT_TEAM * FH_WG * ppt) return ppt;
+  return 0;
+}
+
+template <int PPT, int KIND>
+static void launch_fused_pk(fh_ctx* c, const FusedP& p, unsigned grid) {
+  if (c->nt_loads) k_fused_dense<PPT, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fused_dense<PPT, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+}
+template <int PPT>
+static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid) {
+  switch (c->prox_kind) {
+    case FH_PROX_SHRINK: launch_fused_pk<PPT, PX_SHRINK>(c, p, grid); break;
+    case FH_PROX_NONNEG: launch_fused_pk<PPT, PX_NONNEG>(c, p, grid); break;
+    case FH_PROX_LINF:   launch_fused_pk<PPT, PX_LINF>(c, p, grid); break;
+    case FH_PROX_L1BALL: launch_fused_pk<PPT, PX_L1BALL>(c, p, grid); break;
+    case FH_PROX_BOX:    launch_fused_pk<PPT, PX_BOX>(c, p, grid); break;
+    default:             launch_fused_pk<PPT, PX_IDENTITY>(c, p, grid); break;
+  }
+}
+
+static int launch_fused_dense(fh_ctx* c, double tau, int mode, double* g1) {
+  const int ppt = fused_ppt(c);
+  if (!ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs dense A with n = 4096*{1,2,4,8,16})");
+  FusedP p;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.nteams = (uint32_t)(c->ncu / FT_TEAM);
+  p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
+  p.x0 = c->X[c->xc]; p.g0 = c->G[c->gc]; p.xhat = c->xhat; p.xp = c->P[c->pc ^ 1];
+  p.b = c->b; p.z = c->Z[c->zc ^ 1]; p.tau = tau; p.loss = c->loss_kind; p.mode = mode;
+  p.px = make_prox(c, tau);
+  const unsigned grid = p.nteams * FT_TEAM;
+  const size_t slots_elems = (size_t)c->mp * FT_TEAM;
+  const size_t gpart_elems = (size_t)p.nteams * c->ld;
+  FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
+  p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
+  p.g1 = g1;
+  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  p.out = scalar_out(c);
+  t_begin(c, FH_K_FUSED);
+  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
+  HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
+  switch (ppt) {
+    case 1: launch_fused_p<1>(c, p, grid); break;
+    case 2: launch_fused_p<2>(c, p, grid); break;
+    case 4: launch_fused_p<4>(c, p, grid); break;
+    case 8: launch_fused_p<8>(c, p, grid); break;
+    default: launch_fused_p<16>(c, p, grid); break;
+  }
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---- operator-generic wrappers ---------------------------------------------------------------------
 static int op_fwd(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                   double* xhat, double* xp, double* z, int sub_b) {
@@ -844,6 +911,37 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
   io.x1 = c->X[c->xc ^ 1]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
   c->last_accel = accel != 0;
   FH_TRY(op_adj(c, io));
+  return fetch_scalars(c, scalars);
+}
+
+extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
+  if (!c || !yes) return fail(FH_E_ARG, "null argument");
+  *yes = fused_ppt(c) ? 1 : 0;
+  return 0;
+}
+
+// One-pass FBS iteration: K-fwd and K-adj of the same tau from a single read of A (no acceleration).
+// Writes the complete FH_S_* block; scalars[15] != 0 reports a spin timeout (results invalid: use the two-launch path).
+extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
+  const bool sharded = c->comm != nullptr;
+  double* g1 = c->G[c->gc ^ 1];
+  FH_TRY(launch_fused_dense(c, tau, sharded ? 2 : 0, g1));
+  c->last_accel = false;
+  if (sharded) {
+    t_begin(c, FH_K_COMM);
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    t_end(c, FH_K_COMM);
+    AdjIO io;
+    io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 0; io.coef = 0.0; io.mode = 0; io.tau = tau;
+    io.x0 = c->X[c->xc]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+    io.x1 = c->X[c->xc ^ 1]; io.g1 = g1; io.g0 = c->G[c->gc];
+    FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ));
+  }
   return fetch_scalars(c, scalars);
 }
 

@@ -19,7 +19,7 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 (S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, S_GSUM, S_GMAX, S_RDOT, S_DXDG, S_DG2, S_FSQ_ADJ, S_XH2_ADJ,
  S_GSUM_ADJ, S_GMAX_ADJ, S_ALPHA) = range(15)
 NSCALARS = 16
-K_FWD, K_ADJ, K_AUX, K_COMM = range(4)
+K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT) = range(9)
 UNIQUE_ID_BYTES = 128
@@ -52,6 +52,8 @@ SIGNATURES = {
     "fh_fwd": (_i32, [_ctx, _dbl, _pd]),
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
+    "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_step": (_i32, [_ctx, _dbl, _pd]),
     "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
     "fh_comm_unique_id": (_i32, [C.c_void_p]),
     "fh_comm_init": (_i32, [_ctx, _i32, _i32, C.c_void_p]),
@@ -209,6 +211,18 @@ class HipContext:
 
     def adj(self, tau, accel=False, coef=0.0):
         self._call("fh_adj", float(tau), 1 if accel else 0, float(coef), self._scal_p)
+        return self._scal.copy()
+
+    def fused_supported(self):
+        yes = _i32(0)
+        self._call("fh_fused_supported", C.byref(yes))
+        return bool(yes.value)
+
+    def step(self, tau):
+        """One-pass K-fwd + K-adj (no acceleration).  Raises if the bounded spins timed out."""
+        self._call("fh_step", float(tau), self._scal_p)
+        if self._scal[15] != 0.0:
+            raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()
 
     def commit(self, save_best=False):

@@ -93,8 +93,13 @@ class FBSolver:
     def __init__(self, A, loss, prox, x0, adaptive=True, accelerate=False, verbose=True, max_iters=1000,
                  tolerance=1e-5, stop_rule=stopping.hybrid_residual, L=None, tau0=None, backtrack=True,
                  stepsize_shrink=None, window=10, max_backtracks=20, restart=True, evaluate_objective=False,
-                 record_iterates=False, func=None):
+                 record_iterates=False, func=None, *, fused="auto"):
+        """Reference options (fasta/__init__.py:42-53) plus one build-only, keyword-only switch:
+        fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step`, csrc/fh_fused.h) when the
+        operator shape supports it and acceleration is off.  It is speculative: the launch assumes the step is
+        accepted; when the backtracking test fails the iteration falls back to K-fwd/K-adj (same results)."""
         self.A, self.loss, self.prox = A, loss, prox
+        self.fused_opt = fused
         self.ctx = A.ctx
         self.x0 = np.asarray(x0, dtype=np.float64)
         self.shape = self.x0.shape
@@ -155,6 +160,11 @@ class FBSolver:
         if self.func:                                                   # :149-151
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
+        self.use_fused = (self.fused_opt is not False) and (not self.accelerate) and c.fused_supported()
+        if self.fused_opt is True and not self.use_fused:
+            raise ValueError("fused=True needs a dense operator with n = 4096*{1,2,4,8,16} and accelerate=False")
+        self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
+        self.fused_steps = 0
         self.alpha1 = 1.0                                               # :157
         self.max_residual = -np.inf                                     # :165-167
         self.best_quality = np.inf
@@ -171,7 +181,19 @@ class FBSolver:
         tau = self.tau_next                                             # :178
 
         fval = self._fval
-        s = c.fwd(tau)                                                  # :181-188  (K-fwd)
+        a = None
+        if self.use_fused and self._spec_cooldown == 0:
+            try:
+                s = c.step(tau)                                         # one pass over A: K-fwd and K-adj together
+                a = s
+                self.fused_steps += 1
+            except hip.HipError as exc:                                 # bounded-spin timeout: never speculate again
+                warnings.warn(f"fused one-pass kernel disabled: {exc}")
+                self.use_fused = False
+                s = c.fwd(tau)
+        else:
+            s = c.fwd(tau)                                              # :181-188  (K-fwd)
+            self._spec_cooldown = max(self._spec_cooldown - 1, 0)
         f1 = fval(s[hip.S_FSQ])
         bt = 0
         if self.backtrack:                                              # :195-217
@@ -182,7 +204,10 @@ class FBSolver:
                 s = c.fwd(tau)                                          # :207-213  (K-fwd again)
                 f1 = fval(s[hip.S_FSQ])
                 bt += 1
+                a = None                                                # a speculative K-adj (if any) is void
             self.total_backtracks += bt
+            if bt:
+                self._spec_cooldown = 8
 
         alpha0, coef = 0.0, 0.0
         if self.accelerate:                                             # :220-238
@@ -194,7 +219,8 @@ class FBSolver:
             self.alpha1 = (1 + np.sqrt(1 + 4 * alpha0 ** 2)) / 2
             coef = (alpha0 - 1) / self.alpha1
 
-        a = c.adj(tau, self.accelerate, coef)                           # :242-248  (K-adj)
+        if a is None:
+            a = c.adj(tau, self.accelerate, coef)                       # :242-248  (K-adj)
         if self.accelerate:
             f1 = fval(a[hip.S_FSQ_ADJ])                                 # :245
             xh2, gsum, gmax = a[hip.S_XH2_ADJ], a[hip.S_GSUM_ADJ], a[hip.S_GMAX_ADJ]
@@ -265,7 +291,7 @@ class FBSolver:
 
 def fasta(A, *operands, **options):
     """Run FASTA on the MI355X.  Same positional forms, keyword options and defaults as the reference
-    (fasta/__init__.py:38-53); returns `Convergence`."""
+    (fasta/__init__.py:38-53); returns `Convergence`.  Build-only keyword: fused="auto"|True|False (see FBSolver)."""
     if len(operands) == 6:
         At, f, gradf, g, proxg, x0 = operands
     elif len(operands) == 5:

@@ -76,7 +76,7 @@ enum fh_scalar {
   FH_NSCALARS = 16
 };
 
-enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_NKERNELS = 4 };
+enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_K_FUSED = 4, FH_NKERNELS = 5 };
 
 enum fh_tuning_key {
   FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8, 16 (0 = auto)        */
@@ -136,6 +136,13 @@ int fh_fwd(fh_ctx* ctx, double tau, double* scalars);
  * x1 = xprox + coef*(xprox - x_accel0) (coef = 0 and accel = 0 without acceleration, :242-243);
  * g1 = A^H (z1' - b) (:248); reductions FH_S_DXDG..FH_S_GMAX_ADJ (:254-260, 274, 285).          */
 int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
+/* ONE-PASS iteration (dense operator, no acceleration): K-fwd and K-adj of the same tau from a SINGLE read of A
+ * (teams of 8 co-resident workgroups exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
+ * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it
+ * speculatively: if the backtracking test on FH_S_FSQ fails it re-runs fh_fwd (smaller tau) + fh_adj.
+ * fh_fused_supported says whether the operator shape qualifies (n = 4096*{1,2,4,8,16}, CU count divisible by 8).  */
+int fh_fused_supported(fh_ctx* ctx, int* yes);
+int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
  * copies x1 into FH_VEC_BEST (:298-300).                                                         */
 int fh_commit(fh_ctx* ctx, int save_best);

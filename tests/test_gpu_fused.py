@@ -1,0 +1,113 @@
+"""The one-pass (fused) iteration kernel: same numbers as K-fwd + K-adj, same solves as the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from fasta_python_amd import hip
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
+    c = op.ctx
+    c.set_loss_lsq(b)
+    c.set_prox(prox, mu)
+    c.set_vector(hip.VEC_X0, x0)
+    c.init()
+    return c
+
+
+@pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384)])
+def test_fused_step_equals_two_launch_step(m, n):
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b, x0 = rng.randn(m), rng.randn(n) * 0.05
+    tau, mu = 0.4, 0.03
+    op = fa.DenseMatrixMap(A)
+    try:
+        c = _state(op, b, mu, x0)
+        assert c.fused_supported()
+        s = c.fwd(tau)
+        a = c.adj(tau)
+        ref = {k: c.get_vector(k, n) for k in (hip.VEC_XHAT, hip.VEC_XPROX, hip.VEC_G1)}
+        zref = c.get_vector(hip.VEC_Z, m)
+        c = _state(op, b, mu, x0)
+        f = c.step(tau)
+        for k in (hip.S_FSQ, hip.S_DXG0, hip.S_DX2, hip.S_XH2, hip.S_G02, hip.S_GSUM, hip.S_GMAX):
+            np.testing.assert_allclose(f[k], s[k], rtol=1e-12, atol=1e-300, err_msg=f"fwd scalar {k}")
+        for k in (hip.S_DXDG, hip.S_DG2):
+            np.testing.assert_allclose(f[k], a[k], rtol=1e-10, atol=1e-18, err_msg=f"adj scalar {k}")
+        assert np.array_equal(c.get_vector(hip.VEC_XHAT, n), ref[hip.VEC_XHAT])
+        assert np.array_equal(c.get_vector(hip.VEC_XPROX, n), ref[hip.VEC_XPROX])
+        np.testing.assert_allclose(c.get_vector(hip.VEC_Z, m), zref, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), ref[hip.VEC_G1], rtol=1e-11, atol=1e-15)
+        # against NumPy directly
+        xp = fo.shrink(x0 - tau * (A.T @ (A @ x0 - b)), tau * mu)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), A.T @ (A @ xp - b), rtol=1e-10, atol=1e-14)
+        # repeatable
+        c = _state(op, b, mu, x0)
+        f2 = c.step(tau)
+        assert np.array_equal(f, f2)
+    finally:
+        op.close()
+
+
+def test_unsupported_shape_reports_and_auto_falls_back():
+    A = np.random.RandomState(0).randn(20, 300)
+    op = fa.DenseMatrixMap(A)
+    try:
+        assert not op.ctx.fused_supported()
+        ls, reg = fa.LeastSquares(np.ones(20)), fa.Shrink(0.1)
+        with pytest.raises(ValueError):
+            fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(300), verbose=False, fused=True, max_iters=2)
+        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(300), verbose=False, max_iters=2, tolerance=0.0)
+        assert c.iteration_count == 2
+    finally:
+        op.close()
+
+
+@pytest.mark.parametrize("kind", ["shrink", "nonneg", "backtracking"])
+def test_full_solve_with_fused_steps_matches_oracle(kind):
+    rng = np.random.RandomState(5)
+    m, n = 700, 4096
+    A = rng.randn(m, n)
+    if kind != "backtracking":
+        A /= np.linalg.norm(A, 2)
+    x_true = np.zeros(n); x_true[rng.permutation(n)[:20]] = 1
+    b = A @ x_true + 0.01 * rng.randn(m)
+    opts = dict(tolerance=1e-6, max_iters=80, evaluate_objective=True, record_iterates=True)
+    if kind == "backtracking":
+        opts.update(L=1.0, tau0=1.0, max_iters=40, tolerance=0.0)     # unnormalised A: forces backtracks -> fallback path
+    mu = 0.02
+    reg = fa.NonNeg() if kind == "nonneg" else fa.Shrink(mu)
+    P = pr.nn_least_squares_from(A, b) if kind == "nonneg" else pr.sparse_least_squares_from(A, b, mu)
+    ls = fa.LeastSquares(b)
+    op = fa.DenseMatrixMap(A)
+    try:
+        solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, fused=True, **opts)
+        np.random.seed(3)
+        got = solver.setup().run()
+        np.random.seed(3)
+        two = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=False, **opts)
+    finally:
+        op.close()
+    np.random.seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    assert solver.fused_steps > 0
+    assert got.iteration_count == want.iteration_count == two.iteration_count
+    assert got.backtracks == want.backtracks == two.backtracks
+    if kind == "backtracking":
+        assert got.backtracks > 0 and solver.fused_steps < got.iteration_count
+    k = got.iteration_count
+    rtol = 1e-6
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(got, f)[:k], getattr(want, f)[:k], rtol=rtol, err_msg=f)
+        np.testing.assert_allclose(getattr(got, f)[:k], getattr(two, f)[:k], rtol=1e-8, err_msg=f)
+    np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=rtol)
+    np.testing.assert_allclose(got.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
