@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=8192)
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--tune", default="", help="comma list key=value of FH_TUNE_* integers, e.g. 3=2,0=8")
+    ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"],
+                    help="one-pass iteration kernel (fh_step): auto = when the shape supports it")
     return ap.parse_args()
 
 
@@ -229,7 +231,8 @@ def main():
 
     total = args.warmup + args.steps
     solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=True, accelerate=False, verbose=False,
-                         max_iters=total, tolerance=0.0, backtrack=True, evaluate_objective=False)
+                         max_iters=total, tolerance=0.0, backtrack=True, evaluate_objective=False,
+                         fused={"auto": "auto", "on": True, "off": False}[args.fused])
     np.random.seed(3)           # same Lipschitz probes on every rank
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
@@ -252,15 +255,18 @@ def main():
     fwd_ms, fwd_cnt = ctx.timing_get(hip.K_FWD)
     adj_ms, adj_cnt = ctx.timing_get(hip.K_ADJ)
     comm_ms, comm_cnt = ctx.timing_get(hip.K_COMM)
+    fus_ms, fus_cnt = ctx.timing_get(hip.K_FUSED)
     # algorithmic bytes per launch (DESIGN.md section "byte model")
     bytes_fwd = (m_local * n + 2 * n + m_local + 2 * n + m_local) * 8
     bytes_adj = (m_local * n + 2 * m_local + 4 * n + n) * 8
-    per = {"fasta_fwd(k_fwd_dense)": (fwd_ms, fwd_cnt, bytes_fwd), "fasta_adj(k_adj_dense)": (adj_ms, adj_cnt, bytes_adj)}
+    per = {"fasta_fwd(k_fwd_dense)": (fwd_ms, fwd_cnt, bytes_fwd), "fasta_adj(k_adj_dense)": (adj_ms, adj_cnt, bytes_adj),
+           # one launch = both directions: priced at the two-pass algorithmic bytes of SURVEY.md 8(d); it MOVES half
+           "fasta_step(k_fused_dense)": (fus_ms, fus_cnt, bytes_fwd + bytes_adj)}
     dom = max(per, key=lambda k: per[k][0])
     dms, dcnt, dbytes = per[dom]
     achieved = dbytes / (dms / dcnt * 1e-3) / 1e9 if dcnt else 0.0
-    loop_bytes = fwd_cnt * bytes_fwd + adj_cnt * bytes_adj
-    traffic, traffic_src = (pmc_traffic("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>")
+    loop_bytes = fwd_cnt * bytes_fwd + adj_cnt * bytes_adj + fus_cnt * (bytes_fwd + bytes_adj)
+    traffic, traffic_src = (pmc_traffic("k_fused_dense" if "fused" in dom else ("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>"))
                             if (m_total, n, grp.world) == (65536, 65536, 1) else (None, None))
     ceil_ms, ceil_bytes = ctx.stream_read_ms(2)
 
@@ -290,7 +296,10 @@ def main():
                      "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1] if v[1] else None,
                                         "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9 if v[1] else None} for k, v in per.items()},
                      "loop_GB/s_wallclock": loop_bytes / elapsed / 1e9,
-                     "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None},
+                     "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None,
+                     "fused_one_pass_steps": solver.fused_steps,
+                     "note": ("achieved = algorithmic (two-pass) bytes / launch time; the fused one-pass kernel reads A once, "
+                              "so its HBM traffic is about half of algorithmic_bytes_per_launch" if "fused" in dom else None)},
     }
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(A, b, mu, n, m_total, args.cpu_sample_rows, args.cpu_iters)
