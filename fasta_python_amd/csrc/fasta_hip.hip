@@ -759,8 +759,8 @@ static int fused_ppt(fh_ctx* c) {          // pieces per lane, or 0 when the sha
 
 template <int PPT, int KIND>
 static void launch_fused_pk(fh_ctx* c, const FusedP& p, unsigned grid) {
-  if (c->nt_loads) k_fused_dense<PPT, 1, KIND><<<dim3(grid), dim3(FT_THREADS), 0, c->stream>>>(p);
-  else k_fused_dense<PPT, 0, KIND><<<dim3(grid), dim3(FT_THREADS), 0, c->stream>>>(p);
+  if (c->nt_loads) k_fused_dense<PPT, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else k_fused_dense<PPT, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 template <int PPT>
 static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid) {

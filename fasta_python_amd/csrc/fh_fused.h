@@ -4,22 +4,17 @@
 // Why it is possible: g1 = sum_i a_i * r_i with r_i = grad f(a_i . xprox) -- row i is needed twice, first
 // whole (the dot product), then again for the rank-1 update.  A 512 KiB row does not fit one CU, so a TEAM of
 // 8 co-resident workgroups splits the columns: each member keeps its 1/8 of the row (PPT 16-byte pieces per
-// lane) IN REGISTERS (x and g1 slices in LDS), publishes its partial dot product as one write-through (`sc1`) 8-byte store into the
+// lane) IN REGISTERS, publishes its partial dot product as one write-through (`sc1`) 8-byte store into the
 // row's 64-byte slot line, polls the other seven (bounded spin), sums the eight partials in member order,
-// and applies r_i * (its row pieces) to its LDS-resident slice of g1.  Three row buffers rotate so that
+// and applies r_i * (its row pieces) to its register-resident slice of g1.  Three row buffers rotate so that
 // two rows of loads are in flight while a row's partials are being exchanged (hand-off latency ~1-3 us per
 // the CDNA4 guide's price list vs ~2.4 us of streaming per row per CU).  The prox'd x slice also lives in
 // registers, computed once per launch.
 //
-//   grid  = (#CUs / 8) teams x 8 members, 1 workgroup per CU (128 KiB of LDS: the x and g1 slices), so
+//   grid  = (#CUs / 8) teams x 8 members, 256 threads, 1 workgroup per CU (~330 VGPRs => 1 wave per SIMD), so
 //           the whole grid is co-resident by construction; every spin is bounded by wall-clock and raises
 //           p.err instead of hanging if that assumption is ever violated.
-//   320 threads = 4 compute waves (one per SIMD, all the matrix loads) + 1 COMM wave that only publishes/polls:
-//           `vmcnt` retires in order, so a wave that polls with vector loads would first wait for its own
-//           prefetched rows -- the comm wave has nothing else in flight.
 //   team t owns rows [t*rows_per_team, ...); member j owns 16-byte pieces [j*256*PPT, (j+1)*256*PPT).
-//   blockIdx = member*nteams + team: the members of a team are 32 blocks apart, i.e. on one XCD under the
-//           observed round-robin placement (speed only; correctness never depends on placement).
 //   After the rows: slice partials -> workspace, bounded grid barrier, then all workgroups sum the team
 //   partials for their share of the columns in team order and run the n-side epilogue (same arithmetic as
 //   K-adj's finaliser), last arriver sums the scalars.  No float atomics: bitwise repeatable.
@@ -34,7 +29,6 @@
 #define FT_TEAM 8
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock
-#define FT_THREADS 320                              // 4 compute waves + 1 comm wave
 
 struct FusedP {
   const double* A;
@@ -61,49 +55,22 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-// block_reduce over the 4 compute waves of a 5-wave workgroup (the comm wave only joins the barriers)
-template <int K>
-__device__ __forceinline__ void ft_reduce(double (&v)[K], double* scr, int maxslot) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave < 4) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      v[k] = (k == maxslot) ? wave_max(v[k]) : wave_sum(v[k]);
-      if (lane == 0) scr[wave * K + k] = v[k];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k == maxslot) v[k] = fmax(fmax(scr[k], scr[K + k]), fmax(scr[2 * K + k], scr[3 * K + k]));
-      else v[k] = ((scr[k] + scr[K + k]) + scr[2 * K + k]) + scr[3 * K + k];
-    }
-  }
-  __syncthreads();
-}
-
 template <int PPT, int NT, int KIND>
-__global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
-  // the member's prox'd x slice and its g1 slice live in LDS (2 x 64 KiB at PPT = 16): with the comm wave a SIMD
-  // hosts two waves, so a wave may use at most 256 registers -- three row buffers (192) is all that fits
-  __shared__ __attribute__((aligned(16))) d2 s_xq[FH_WG * PPT];
-  __shared__ __attribute__((aligned(16))) d2 s_ga[FH_WG * PPT];
+__global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i, loss term
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t team = blockIdx.x % p.nteams, mem = blockIdx.x / p.nteams;
-  const bool comm = wave == 4;                                   // the polling wave: no matrix traffic
-  const uint32_t c0 = mem * (FH_WG * PPT) + (comm ? 0u : tid);   // first 16-byte piece of this lane; next at +256
+  const uint32_t team = blockIdx.x / FT_TEAM, mem = blockIdx.x % FT_TEAM;
+  const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
   const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
+  d2 xq[PPT];
   double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax, (rdot unused: no acceleration here)
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    if (comm) continue;
     const uint32_t c = c0 + k * FH_WG;
     const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
     const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
@@ -126,8 +93,7 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
         v[5] = fmax(v[5], fabs(xpe));
       }
     }
-    s_xq[tid + k * FH_WG] = xp;
-    s_ga[tid + k * FH_WG] = (d2){0.0, 0.0};
+    xq[k] = xp;
     if (team == 0) {            // write-through: other workgroups read these back after the grid barrier
       store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
       store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
@@ -138,30 +104,33 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
   const uint32_t r_begin = min(team * p.rows_per_team, p.mp);
   const uint32_t r_end = min(r_begin + p.rows_per_team, p.mp);
   const d2* Abase = reinterpret_cast<const d2*>(p.A) + c0;
+  d2 ga[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
   double fs = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
 
   auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
-    if (r < r_end && !comm) {
+    if (r < r_end) {
       const d2* src = Abase + (uint64_t)r * p.ld2;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + k * FH_WG);
     }
   };
-  auto process_row = [&](d2 (&buf)[PPT], uint32_t r) {            // r < r_end, uniform over the workgroup
-    if (!comm) {
-      double part = 0.0;
+  // `vmcnt` retires in order: the polling wave (0) must not have a freshly issued row ahead of its poll loads, so it
+  // issues the reload of the freed buffer AFTER the poll; waves 1-3 issue it up front (two rows in flight).
+  auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
+    if (wave != 0) load_row(nbuf, nr);
+    double part = 0.0;
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) {
-        const d2 xv = s_xq[tid + k * FH_WG];
-        part = fma(buf[k].x, xv.x, part);
-        part = fma(buf[k].y, xv.y, part);
-      }
-      part = wave_sum(part);
-      if (lane == 0) s_part[wave] = part;
+    for (int k = 0; k < PPT; ++k) {
+      part = fma(buf[k].x, xq[k].x, part);
+      part = fma(buf[k].y, xq[k].y, part);
     }
+    part = wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    if (comm) {
+    if (wave == 0) {
       double* line = p.slots + (uint64_t)r * FT_TEAM;
       if (lane == 0) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
       double val = 0.0;
@@ -170,17 +139,19 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
         for (;;) {
           val = load_partial(line + lane);
           if (!ft_is_sentinel(val)) break;
-          if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS ||
-              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+              __builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
             __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             val = 0.0;
             break;
           }
+          __builtin_amdgcn_s_sleep(1);
         }
       }
       double zs = __shfl(val, 0, 64);
 #pragma unroll
       for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
+      load_row(nbuf, nr);                                           // wave 0's deferred prefetch
       if (lane == 0) {
         const double bi = p.b[r];
         s_bc[0] = loss_grad(zs, bi, p.loss);
@@ -189,16 +160,12 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
       }
     }
     __syncthreads();
-    if (!comm) {
-      const double rv = s_bc[0];
-      if (tid == 0 && mem == 0) fs += s_bc[1];
+    const double rv = s_bc[0];
+    if (tid == 0 && mem == 0) fs += s_bc[1];
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) {
-        d2 g = s_ga[tid + k * FH_WG];
-        g.x = fma(buf[k].x, rv, g.x);
-        g.y = fma(buf[k].y, rv, g.y);
-        s_ga[tid + k * FH_WG] = g;
-      }
+    for (int k = 0; k < PPT; ++k) {
+      ga[k].x = fma(buf[k].x, rv, ga[k].x);
+      ga[k].y = fma(buf[k].y, rv, ga[k].y);
     }
   };
 
@@ -207,25 +174,20 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
     load_row(b0, r_begin);
     load_row(b1, r_begin + 1u);
     for (uint32_t r = r_begin; r < r_end; r += 3u) {
-      load_row(b2, r + 2u);
-      process_row(b0, r);
-      load_row(b0, r + 3u);
-      if (r + 1u < r_end) process_row(b1, r + 1u);
-      load_row(b1, r + 4u);
-      if (r + 2u < r_end) process_row(b2, r + 2u);
+      process_row(b0, r, b2, r + 2u);
+      if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
+      if (r + 2u < r_end) process_row(b2, r + 2u, b1, r + 4u);
       if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
     }
   }
 
   // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------
-  if (!comm) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k)
-      store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, s_ga[tid + k * FH_WG]);
-  }
+  for (int k = 0; k < PPT; ++k)
+    store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
   {
     double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], 0.0};
-    ft_reduce<8>(w, s_scr, 6);
+    block_reduce<8>(w, s_scr, 6);
     if (tid == 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + k, w[k]);
@@ -253,7 +215,7 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
   e.accel = 0; e.coef = 0.0; e.tau = p.tau;
   double u[5] = {0, 0, 0, 0, 0};                     // dxdg, dg2, xh2, gsum, gmax
   const uint32_t share = (p.ld2 + gridDim.x - 1) / gridDim.x;
-  for (uint32_t t = tid; t < share && !comm; t += FH_WG) {         // compute waves only
+  for (uint32_t t = tid; t < share; t += FH_WG) {
     const uint32_t c = blockIdx.x * share + t;
     if (c >= p.ld2) continue;
     const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
@@ -270,7 +232,7 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
       bb_element(e, g.y, x0v.y, xpv.y, 0.0, xhv.y, 2u * c + 1u < p.n, u);
     }
   }
-  ft_reduce<5>(u, s_scr, 4);
+  block_reduce<5>(u, s_scr, 4);
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + 8 + k, u[k]);
@@ -278,7 +240,6 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
   if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
   double w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
-    if (comm) break;
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
       const double q = load_partial(p.red + (uint64_t)i * 16 + k);
@@ -287,9 +248,9 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_fused_dense(const FusedP p) {
   }
   {
     double a[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], 0.0};
-    ft_reduce<8>(a, s_scr, 6);
+    block_reduce<8>(a, s_scr, 6);
     double bq[5] = {w[8], w[9], w[10], w[11], w[12]};
-    ft_reduce<5>(bq, s_scr, 4);
+    block_reduce<5>(bq, s_scr, 4);
     if (tid == 0) {
       p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
       p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = 0.0;
