@@ -145,6 +145,7 @@ struct fh_ctx {
   int tv_u = 8;
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
+  int fused_variant = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
@@ -335,6 +336,8 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       c->tv_rows = (int)value; return 0;
     case FH_TUNE_TV_NT:
       c->tv_nt = value ? 1 : 0; return 0;
+    case FH_TUNE_FUSED_VARIANT:
+      c->fused_variant = (int)value; return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
   }
 }
@@ -790,7 +793,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, int mode, double* g1) {
   FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
   p.g1 = g1;
-  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR; p.variant = c->fused_variant;
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
   HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));

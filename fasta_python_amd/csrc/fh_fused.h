@@ -48,6 +48,7 @@ struct FusedP {
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
   unsigned* err;         // set to 1 on a spin timeout
+  int variant;           // tuning bits: 1 = polling wave defers its prefetch, 2 = members of a team 32 blocks apart (one XCD), 4 = no s_sleep in the poll
   double* out;
 };
 
@@ -62,7 +63,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t team = blockIdx.x / FT_TEAM, mem = blockIdx.x % FT_TEAM;
+  const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / FT_TEAM;
+  const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % FT_TEAM;
+  const bool defer = (p.variant & 1) != 0;
   const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
   const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
 
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // `vmcnt` retires in order: the polling wave (0) must not have a freshly issued row ahead of its poll loads, so it
   // issues the reload of the freed buffer AFTER the poll; waves 1-3 issue it up front (two rows in flight).
   auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
-    if (wave != 0) load_row(nbuf, nr);
+    if (wave != 0 || !defer) load_row(nbuf, nr);
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
             val = 0.0;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
         }
       }
       double zs = __shfl(val, 0, 64);
 #pragma unroll
       for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
-      load_row(nbuf, nr);                                           // wave 0's deferred prefetch
+      if (defer) load_row(nbuf, nr);                                // wave 0's deferred prefetch
       if (lane == 0) {
         const double bi = p.b[r];
         s_bc[0] = loss_grad(zs, bi, p.loss);

@@ -21,7 +21,7 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
- TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT) = range(9)
+ TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT) = range(10)
 UNIQUE_ID_BYTES = 128
 
 _u64, _i32, _dbl = C.c_uint64, C.c_int, C.c_double

@@ -87,7 +87,8 @@ enum fh_tuning_key {
   FH_TUNE_NT_LOADS = 5,      /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
   FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads in flight per lane (2, 4, 8)           */
   FH_TUNE_TV_ROWS = 7,       /* stencil kernels: image rows per workgroup (0 = auto)                 */
-  FH_TUNE_TV_NT = 8          /* stencil kernels: non-temporal loads/stores (default 0)               */
+  FH_TUNE_TV_NT = 8,         /* stencil kernels: non-temporal loads/stores (default 0)               */
+  FH_TUNE_FUSED_VARIANT = 9  /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h)   */
 };
 
 /* ---- library / context -------------------------------------------------------------- */
