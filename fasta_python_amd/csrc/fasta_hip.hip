@@ -145,7 +145,7 @@ struct fh_ctx {
   int tv_u = 8;
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
-  int fused_variant = 0;
+  int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
