@@ -339,12 +339,21 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused3_dense(const FusedP p) {
   double fs = 0.0;
   bool dead = false;
 
+  // Branch-free hot loop: a wave with fewer than MAXJ lane-columns re-loads its last one (clamped offset) and
+  // gives the duplicate a zero weight in the dot product; its dummy accumulator is never stored.
+  uint32_t joff[MAXJ];
+  double jw[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const bool real = (uint32_t)j < nj;
+    joff[j] = (real ? (uint32_t)j : (nj ? nj - 1u : 0u)) * 64u;
+    jw[j] = real ? 1.0 : 0.0;
+  }
   auto load_row = [&](d2 (&buf)[MAXJ], uint32_t r) {
-    if (r < r_end) {
+    if (r < r_end && !comm) {
       const d2* src = Abase + (uint64_t)r * p.ld2;
 #pragma unroll
-      for (int j = 0; j < MAXJ; ++j)
-        if ((uint32_t)j < nj) buf[j] = load_stream<NT>(src + j * 64);
+      for (int j = 0; j < MAXJ; ++j) buf[j] = load_stream<NT>(src + joff[j]);
     }
   };
   auto process_row = [&](d2 (&buf)[MAXJ], uint32_t r) {          // r < r_end, uniform over the workgroup
@@ -352,11 +361,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused3_dense(const FusedP p) {
       double part = 0.0;
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
-        if ((uint32_t)j < nj) {
-          const d2 xv = s_xq[q0 + j * 64];
-          part = fma(buf[j].x, xv.x, part);
-          part = fma(buf[j].y, xv.y, part);
-        }
+        const d2 xv = s_xq[q0 + joff[j]];
+        double pj = buf[j].x * xv.x;
+        pj = fma(buf[j].y, xv.y, pj);
+        part = fma(pj, jw[j], part);
       }
       part = wave_sum(part);
       if (lane == 0) s_part[wave] = part;
@@ -397,10 +405,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused3_dense(const FusedP p) {
       const double rv = s_bc[0];
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
-        if ((uint32_t)j < nj) {
-          ga[j].x = fma(buf[j].x, rv, ga[j].x);
-          ga[j].y = fma(buf[j].y, rv, ga[j].y);
-        }
+        ga[j].x = fma(buf[j].x, rv, ga[j].x);
+        ga[j].y = fma(buf[j].y, rv, ga[j].y);
       }
     }
   };
