@@ -30,8 +30,6 @@
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock
 
-typedef int ft_v16i __attribute__((ext_vector_type(16)));
-
 struct FusedP {
   const double* A;
   uint64_t ld;
@@ -58,9 +56,7 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-// SP = 1: the slot line is polled with ONE scalar load (s_load_dwordx16, retires on lgkmcnt) instead of eight lanes'
-// vector loads (vmcnt, in-order behind this wave's own prefetched rows).
-template <int PPT, int NT, int KIND, int SP>
+template <int PPT, int NT, int KIND>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i, loss term
@@ -141,30 +137,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       double* line = p.slots + (uint64_t)r * FT_TEAM;
       if (lane == 0) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
       double val = 0.0;
-      if (SP && !dead) {
-        const unsigned long long a = (unsigned long long)line;
-        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a);
-        const unsigned ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        const unsigned long long ua = ((unsigned long long)ahi << 32) | alo;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-          ft_v16i w16;
-          asm volatile("s_dcache_inv\n\ts_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(w16) : "s"(ua) : "memory");
-          bool ready = true;
-#pragma unroll
-          for (int j = 0; j < FT_TEAM; ++j) ready = ready && !((unsigned)w16[2 * j] == FT_SENTINEL_HI && (unsigned)w16[2 * j + 1] == FT_SENTINEL_HI);
-          if (ready) {
-#pragma unroll
-            for (int j = 0; j < FT_TEAM; ++j) if (lane == (uint32_t)j) val = __hiloint2double(w16[2 * j + 1], w16[2 * j]);
-            break;
-          }
-          if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS ||
-              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      } else if (!SP && lane < FT_TEAM && !dead) {
+      if (lane < FT_TEAM && !dead) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
           val = load_partial(line + lane);
