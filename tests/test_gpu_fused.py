@@ -112,3 +112,29 @@ def test_full_solve_with_fused_steps_matches_oracle(kind):
         np.testing.assert_allclose(getattr(got, f)[:k], getattr(two, f)[:k], rtol=1e-6, err_msg=f)
     np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=rtol)
     np.testing.assert_allclose(got.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
+
+
+def test_fused_step_on_the_row_sharded_path_with_one_rank():
+    """fh_step with a communicator: local one-pass kernel -> RCCL all-reduce of g1 and ||r||^2 -> n-side epilogue."""
+    rng = np.random.RandomState(11)
+    m, n = 300, 4096
+    A = rng.randn(m, n) / 30
+    b = rng.randn(m)
+    ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+    opts = dict(tolerance=1e-6, max_iters=30, evaluate_objective=True)
+    op = fa.DenseMatrixMap(A)
+    try:
+        np.random.seed(1)
+        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=True, **opts)
+        op.ctx.comm_init(1, 0, hip.comm_unique_id())
+        solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, fused=True, **opts)
+        np.random.seed(1)
+        got = solver.setup().run()
+    finally:
+        op.close()
+    assert solver.fused_steps > 0
+    assert got.iteration_count == ref.iteration_count and got.backtracks == ref.backtracks
+    k = got.iteration_count
+    np.testing.assert_allclose(got.residuals[:k], ref.residuals[:k], rtol=1e-12)
+    np.testing.assert_allclose(got.objectives[:k + 1], ref.objectives[:k + 1], rtol=1e-12)
+    np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
