@@ -264,228 +264,3 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   }
 }
-
-// Same kernel with RS rows per exchange and two rotating buffers of RS rows: `vmcnt` retires in order, so every
-// poll waits for the newest row loads of its wave; exchanging RS rows at a time pays that wait once per RS rows.
-template <int PPT, int NT, int KIND, int RS>
-__global__ __launch_bounds__(FH_WG, 1) void k_fused_rs_dense(const FusedP p) {
-  __shared__ __attribute__((aligned(16))) double s_part[4 * RS];
-  __shared__ __attribute__((aligned(16))) double s_bc[2 * RS];   // broadcast: r_i, loss term per row of the group
-  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
-  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / FT_TEAM;
-  const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % FT_TEAM;
-  const bool defer = (p.variant & 1) != 0;
-  const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
-  const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
-
-  // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
-  d2 xq[PPT];
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax, (rdot unused: no acceleration here)
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const uint32_t c = c0 + k * FH_WG;
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-    const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
-    d2 xh, xp;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const bool valid = (2u * c + e) < p.n;
-      double xhe = fwd_point(x0v[e], g0v[e], p.tau);
-      double xpe = prox_scalar<KIND>(xhe, p.px, level);
-      if (!valid) { xhe = 0.0; xpe = 0.0; }
-      xh[e] = xhe; xp[e] = xpe;
-      if (valid && team == 0) {
-        const double dx = sub_nofma(xpe, x0v[e]);
-        const double dh = sub_nofma(xpe, xhe);
-        v[0] = fma(dx, g0v[e], v[0]);
-        v[1] = fma(dx, dx, v[1]);
-        v[2] = fma(dh, dh, v[2]);
-        v[3] = fma(g0v[e], g0v[e], v[3]);
-        v[4] += fabs(xpe);
-        v[5] = fmax(v[5], fabs(xpe));
-      }
-    }
-    xq[k] = xp;
-    if (team == 0) {            // write-through: other workgroups read these back after the grid barrier
-      store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
-      store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
-    }
-  }
-
-  // ---------------- rows of this team: one pass, three rotating register buffers ----------------------------
-  const uint32_t r_begin = min(team * p.rows_per_team, p.mp);
-  const uint32_t r_end = min(r_begin + p.rows_per_team, p.mp);
-  const d2* Abase = reinterpret_cast<const d2*>(p.A) + c0;
-  d2 ga[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
-  double fs = 0.0;
-  bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
-
-  auto load_group = [&](d2 (&buf)[RS][PPT], uint32_t r) {
-#pragma unroll
-    for (int q = 0; q < RS; ++q) {
-      if (r + q < r_end) {
-        const d2* src = Abase + (uint64_t)(r + q) * p.ld2;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) buf[q][k] = load_stream<NT>(src + k * FH_WG);
-      }
-    }
-  };
-  auto process_group = [&](d2 (&buf)[RS][PPT], uint32_t r) {      // r < r_end, uniform over the workgroup
-    const uint32_t nr = min((uint32_t)RS, r_end - r);
-#pragma unroll
-    for (int q = 0; q < RS; ++q) {
-      if ((uint32_t)q < nr) {
-        double part = 0.0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          part = fma(buf[q][k].x, xq[k].x, part);
-          part = fma(buf[q][k].y, xq[k].y, part);
-        }
-        part = wave_sum(part);
-        if (lane == 0) s_part[q * 4 + wave] = part;
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      double* line = p.slots + (uint64_t)r * FT_TEAM;               // RS consecutive 64-byte lines
-      if (lane < nr) store_partial(line + lane * FT_TEAM + mem,
-                                   ((s_part[lane * 4] + s_part[lane * 4 + 1]) + s_part[lane * 4 + 2]) + s_part[lane * 4 + 3]);
-      double val = 0.0;
-      if (lane < nr * FT_TEAM && !dead) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-          val = load_partial(line + lane);
-          if (!ft_is_sentinel(val)) break;
-          if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-              __builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val = 0.0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < RS; ++q) {
-        double zs = __shfl(val, q * FT_TEAM, 64);
-#pragma unroll
-        for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, q * FT_TEAM + j, 64);   // member order: deterministic
-        if (lane == 0 && (uint32_t)q < nr) {
-          const double bi = p.b[r + q];
-          s_bc[2 * q] = loss_grad(zs, bi, p.loss);
-          s_bc[2 * q + 1] = (r + q) < p.m ? loss_term(zs, bi, p.loss) : 0.0;
-          if (mem == 0) p.z[r + q] = zs;
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RS; ++q) {
-      if ((uint32_t)q < nr) {
-        const double rv = s_bc[2 * q];
-        if (tid == 0 && mem == 0) fs += s_bc[2 * q + 1];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          ga[k].x = fma(buf[q][k].x, rv, ga[k].x);
-          ga[k].y = fma(buf[q][k].y, rv, ga[k].y);
-        }
-      }
-    }
-  };
-
-  {
-    d2 bA[RS][PPT], bB[RS][PPT];
-    load_group(bA, r_begin);
-    for (uint32_t r = r_begin; r < r_end; r += 2u * RS) {
-      load_group(bB, r + RS);
-      process_group(bA, r);
-      load_group(bA, r + 2u * RS);
-      if (r + RS < r_end) process_group(bB, r + RS);
-      if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
-    }
-  }
-
-  // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------
-#pragma unroll
-  for (int k = 0; k < PPT; ++k)
-    store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
-  {
-    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], 0.0};
-    block_reduce<8>(w, s_scr, 6);
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + k, w[k]);
-    }
-  }
-
-  // ---------------- bounded grid barrier (all workgroups are co-resident: one per CU) -----------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
-        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-
-  // ---------------- every workgroup finalises its share of the columns: team-ordered sum + n-side epilogue ----
-  AdjP e;                                            // reuse K-adj's per-element epilogue
-  e.accel = 0; e.coef = 0.0; e.tau = p.tau;
-  double u[5] = {0, 0, 0, 0, 0};                     // dxdg, dg2, xh2, gsum, gmax
-  const uint32_t share = (p.ld2 + gridDim.x - 1) / gridDim.x;
-  for (uint32_t t = tid; t < share; t += FH_WG) {
-    const uint32_t c = blockIdx.x * share + t;
-    if (c >= p.ld2) continue;
-    const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
-    d2 g = {0.0, 0.0};
-#pragma unroll 8
-    for (uint32_t s = 0; s < p.nteams; ++s) g += load_partial2(gp + (uint64_t)s * p.ld2);
-    reinterpret_cast<d2*>(p.g1)[c] = g;
-    if (p.mode == 0) {
-      // xhat / xp were written by team 0 with plain stores earlier in THIS launch: read them back through sc1
-      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-      const d2 xpv = load_partial2(reinterpret_cast<const d2*>(p.xp) + c);
-      const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
-      bb_element(e, g.x, x0v.x, xpv.x, 0.0, xhv.x, 2u * c < p.n, u);
-      bb_element(e, g.y, x0v.y, xpv.y, 0.0, xhv.y, 2u * c + 1u < p.n, u);
-    }
-  }
-  block_reduce<5>(u, s_scr, 4);
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + 8 + k, u[k]);
-  }
-  if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
-  double w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const double q = load_partial(p.red + (uint64_t)i * 16 + k);
-      if (k == 6 || k == 12) w[k] = fmax(w[k], q); else w[k] += q;
-    }
-  }
-  {
-    double a[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], 0.0};
-    block_reduce<8>(a, s_scr, 6);
-    double bq[5] = {w[8], w[9], w[10], w[11], w[12]};
-    block_reduce<5>(bq, s_scr, 4);
-    if (tid == 0) {
-      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
-      p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = 0.0;
-      p.out[S_DXDG] = bq[0]; p.out[S_DG2] = bq[1]; p.out[S_XH2_ADJ] = bq[2]; p.out[S_GSUM_ADJ] = bq[3];
-      p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = a[0];
-      p.out[S_ALPHA] = level;
-      p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
-    }
-  }
-}
