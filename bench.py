@@ -151,7 +151,7 @@ def run_tv(args, grp):
     loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
     total = args.warmup + args.steps
     solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=True, accelerate=False, verbose=False,
-                         max_iters=total, tolerance=0.0)
+                         max_iters=total, tolerance=0.0, fused={"auto": "auto", "on": True, "off": False}[args.fused])
     np.random.seed(3)
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
@@ -171,7 +171,10 @@ def run_tv(args, grp):
     P = side * side
     fwd_ms, fwd_cnt = ctx.timing_get(hip.K_FWD)
     adj_ms, adj_cnt = ctx.timing_get(hip.K_ADJ)
-    per = {"fasta_fwd(k_fwd_tv)": (fwd_ms, fwd_cnt, 64 * P), "fasta_adj(k_adj_tv)": (adj_ms, adj_cnt, 72 * P)}
+    fus_ms, fus_cnt = ctx.timing_get(hip.K_FUSED)
+    per = {"fasta_fwd(k_fwd_tv_step)": (fwd_ms, fwd_cnt, 64 * P), "fasta_adj(k_adj_tv_step)": (adj_ms, adj_cnt, 72 * P),
+           "fasta_step(k_fused_tv_step)": (fus_ms, fus_cnt, 136 * P)}
+    per = {k: v for k, v in per.items() if v[1]}
     dom = max(per, key=lambda k: per[k][0])
     dms, dcnt, dbytes = per[dom]
     achieved = dbytes / (dms / dcnt * 1e-3) / 1e9
@@ -186,10 +189,10 @@ def run_tv(args, grp):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
                      "avg_launch_ms": dms / dcnt, "algorithmic_bytes_per_launch": dbytes,
                      "note": "priced at the materialised-vector model of SURVEY.md 8(d) (64*P / 72*P); this build never "
-                             "materialises the gradient and moves 56*P per launch (fh_tv.h)",
+                             "materialises the gradient: the two step kernels move 56*P each, the one-pass kernel ~60*P for both (fh_tv.h)",
                      "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1], "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9}
                                     for k, v in per.items() if v[1]},
-                     "loop_GB/s_wallclock": (fwd_cnt * 64 * P + adj_cnt * 72 * P) / elapsed / 1e9},
+                     "loop_GB/s_wallclock": (fwd_cnt * 64 * P + adj_cnt * 72 * P + fus_cnt * 136 * P) / elapsed / 1e9},
     }
     print(json.dumps(result))
     A.close()

@@ -919,7 +919,36 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
 
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
-  *yes = fused_ppt(c) ? 1 : 0;
+  // 1 = dense one-pass kernel (speculative: a rejected step costs a wasted A^T half), 2 = stencil one-pass kernel
+  // (costs no more than K-fwd alone, so it simply replaces both launches), 0 = unsupported
+  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (fused_ppt(c) ? 1 : 0);
+  return 0;
+}
+
+static int launch_fused_tv(fh_ctx* c, double tau) {
+  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
+    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
+  if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
+  TvStepFwdP p;
+  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
+  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
+  p.strip_groups = ((p.W + TVF_OWN - 1) / TVF_OWN + 3) / 4;
+  p.x0 = c->X[c->xc]; p.xacc0 = nullptr; p.xp = c->P[c->pc ^ 1]; p.zc = c->zcur; p.b = c->b; p.zn = c->Z[c->zc ^ 1];
+  p.tau = tau;
+  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
+  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
+  t_begin(c, FH_K_FUSED);
+#define TV_FUSED(U, NT)                                                                                            \
+  do {                                                                                                             \
+    if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
+    else k_fused_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
+  } while (0)
+  if (c->tv_nt) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 8) TV_FUSED(8, 1); else TV_FUSED(4, 1); }
+  else { if (c->tv_u == 2) TV_FUSED(2, 0); else if (c->tv_u == 8) TV_FUSED(8, 0); else TV_FUSED(4, 0); }
+#undef TV_FUSED
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -927,6 +956,12 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
 // Writes the complete FH_S_* block; scalars[15] != 0 reports a spin timeout (results invalid: use the two-launch path).
 extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
+  if (c->op == OP_STENCIL) {
+    if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+    FH_TRY(launch_fused_tv(c, tau));
+    c->last_accel = false;
+    return fetch_scalars(c, scalars);
+  }
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   const bool sharded = c->comm != nullptr;
   double* g1 = c->G[c->gc ^ 1];

@@ -447,3 +447,171 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv_step(const TvStepAdjP p) {
     __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+// =================================================================================================
+// ONE-PASS FBS iteration for the stencil pair (no acceleration): everything k_fwd_tv_step does PLUS the
+// K-adj reductions, because g1 = grad(z_new - b) is a 2-point difference of values this sweep has just
+// produced (previous row: a register; left column: __shfl_up).  Per pixel it reads x0 16 + z_cur 8 + b 8 and
+// writes xprox 16 + z_new 8 -- the traffic of K-fwd alone; K-adj's 56*P disappear.
+//   lanes 2..62 own (61 columns per wave): lane 0 supplies r_cur to lane 1, lanes 1 and 63 supply xprox / z_new
+//   / r_new halos; each workgroup also rolls through one halo row above its chunk (r_new of row i0-1 feeds
+//   g1 of row i0) and looks one row ahead (xprox of row i0+rows feeds z_new of the last row).
+// =================================================================================================
+#define TVF_OWN 61
+
+template <int IDENT, int TV_U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_fused_tv_step(const TvStepFwdP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
+  const uint32_t first = (sg * 4u + wave) * TVF_OWN;
+  // lane L <-> image column first + L - 2 (periodic); lanes 2..62 own
+  const uint32_t cw = (first + lane + 2u * p.W - 2u) % p.W;
+  const uint32_t c = first + lane - 2u;                           // valid as an index only for owning lanes
+  const bool own = lane >= 2u && lane <= 62u && c < p.W;
+  double v[4] = {0, 0, 0, 0};                                     // dxg0, dx2, xh2, g02
+  double u[5] = {0, 0, 0, 0, 0};                                  // dxdg, dg2, xh2(adj), gsum, gmax
+  double fs = 0.0;
+
+  auto row_of = [&](uint32_t base, int off) -> uint32_t {        // (base + off) mod H, periodic
+    const int64_t Hh = (int64_t)p.H;
+    return (uint32_t)((((int64_t)base + off) % Hh + Hh) % Hh);
+  };
+  auto resid_at = [&](uint32_t row) -> double {
+    const uint64_t pix = (uint64_t)row * p.W + cw;
+    return sub_nofma(load_f64<NT>(p.zc + pix), load_f64<NT>(p.b + pix));
+  };
+  // forward point + prox of one pixel from its r_cur neighbourhood
+  auto prox_pixel = [&](d2 x0v, double r_me, double r_up, double r_left, d2& g0v, d2& xh) -> d2 {
+    g0v.x = sub_nofma(r_up, r_me);
+    g0v.y = sub_nofma(r_left, r_me);
+    xh.x = fwd_point(x0v.x, g0v.x, p.tau);
+    xh.y = fwd_point(x0v.y, g0v.y, p.tau);
+    return IDENT ? xh : tv_ball(xh);
+  };
+
+  // ---- prologue: halo row i0-1 (needs r_cur of rows i0-2 and i0-1), then row i0 --------------------------------
+  double rc_up = resid_at(row_of(i0, -2));
+  d2 x0_prev, xh_prev, xp_prev;        // pixel (row-1) state kept for its z_new / epilogue one step later
+  double b_prev, rn_prev = 0.0;        // r_new of the row above the one being finished
+  {
+    const uint32_t hrow = row_of(i0, -1);
+    const uint64_t pix = (uint64_t)hrow * p.W + cw;
+    const d2 x0v = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + pix);
+    b_prev = load_f64<NT>(p.b + pix);
+    const double r_me = sub_nofma(load_f64<NT>(p.zc + pix), b_prev);
+    const double r_left = __shfl_up(r_me, 1, 64);
+    d2 g0v;
+    xp_prev = prox_pixel(x0v, r_me, rc_up, r_left, g0v, xh_prev);
+    x0_prev = x0v;
+    rc_up = r_me;
+  }
+  // process rows t = 0 .. rows: step t loads row i0+t, finishes z_new / epilogue of row i0+t-1
+  // (t = 0 finishes the halo row i0-1: only its r_new is kept)
+  for (uint32_t t0 = 0; t0 <= rows; t0 += TV_U) {
+    d2 xv[TV_U];
+    double zv[TV_U], bv[TV_U];
+    uint64_t npix[TV_U];
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const uint32_t t = min(t0 + q, rows);                        // clamp past the chunk (loads stay in bounds)
+      const uint32_t nrow = row_of(i0, (int)t);
+      npix[q] = (uint64_t)nrow * p.W + cw;
+      xv[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.x0) + npix[q]);
+      zv[q] = load_f64<NT>(p.zc + npix[q]);
+      bv[q] = load_f64<NT>(p.b + npix[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const uint32_t t = t0 + q;
+      if (t <= rows) {                                             // wave-uniform
+        // ---- new row i0+t: forward point + prox (owned when t < rows) ----
+        const double r_n = sub_nofma(zv[q], bv[q]);
+        const double r_left = __shfl_up(r_n, 1, 64);
+        d2 g0v, xh;
+        const d2 xp = prox_pixel(xv[q], r_n, rc_up, r_left, g0v, xh);
+        const bool mine = own && t < rows;
+        if (mine) {
+          store_d2<NT>(reinterpret_cast<d2*>(p.xp) + npix[q], xp);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double dx = sub_nofma(xp[e], xv[q][e]);
+            const double dh = sub_nofma(xp[e], xh[e]);
+            v[0] = fma(dx, g0v[e], v[0]);
+            v[1] = fma(dx, dx, v[1]);
+            v[2] = fma(dh, dh, v[2]);
+            v[3] = fma(g0v[e], g0v[e], v[3]);
+          }
+        }
+        // ---- finish row i0+t-1: z_new, r_new, g1, BB terms ----
+        const double right_y = __shfl_down(xp_prev.y, 1, 64);
+        double zo;
+        {
+#pragma clang fp contract(off)
+          const double a0 = xp.x - xp_prev.x;
+          const double a1 = right_y - xp_prev.y;
+          zo = a0 + a1;
+        }
+        const double rn = sub_nofma(zo, b_prev);
+        const double rn_left = __shfl_up(rn, 1, 64);
+        if (own && t >= 1u) {                                      // rows i0 .. i0+rows-1
+          const uint32_t orow = i0 + t - 1u;
+          store_f64<NT>(p.zn + (uint64_t)orow * p.W + c, zo);
+          fs = fma(rn, rn, fs);
+          d2 g1;
+          g1.x = sub_nofma(rn_prev, rn);
+          g1.y = sub_nofma(rn_left, rn);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double dx = sub_nofma(xp_prev[e], x0_prev[e]);
+            const double dg = bb_dgrad(g1[e], xh_prev[e], x0_prev[e], p.tau);
+            const double dh = sub_nofma(xp_prev[e], xh_prev[e]);
+            u[0] = fma(dx, dg, u[0]);
+            u[1] = fma(dg, dg, u[1]);
+            u[2] = fma(dh, dh, u[2]);
+            u[3] += fabs(xp_prev[e]);
+            u[4] = fmax(u[4], fabs(xp_prev[e]));
+          }
+        }
+        rn_prev = rn;
+        x0_prev = xv[q]; xh_prev = xh; xp_prev = xp; b_prev = bv[q]; rc_up = r_n;
+      }
+    }
+  }
+  double w[8] = {fs, v[0], v[1], v[2], v[3], u[0], u[1], u[2]};
+  block_reduce<8>(w, s_scr, -1);
+  double w2[2] = {u[3], u[4]};
+  block_reduce<2>(w2, s_scr, 1);
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + k, w[k]);
+    store_partial(p.red + (uint64_t)blockIdx.x * 16 + 8, w2[0]);
+    store_partial(p.red + (uint64_t)blockIdx.x * 16 + 9, w2[1]);
+  }
+  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  double t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const double qv = load_partial(p.red + (uint64_t)i * 16 + k);
+      if (k == 9) t[k] = fmax(t[k], qv); else t[k] += qv;
+    }
+  }
+  {
+    double a[8] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]};
+    block_reduce<8>(a, s_scr, -1);
+    double bq[2] = {t[8], t[9]};
+    block_reduce<2>(bq, s_scr, 1);
+    if (tid == 0) {
+      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
+      p.out[S_GSUM] = bq[0]; p.out[S_GMAX] = bq[1]; p.out[S_RDOT] = 0.0;
+      p.out[S_DXDG] = a[5]; p.out[S_DG2] = a[6]; p.out[S_XH2_ADJ] = a[7];
+      p.out[S_GSUM_ADJ] = bq[0]; p.out[S_GMAX_ADJ] = bq[1]; p.out[S_FSQ_ADJ] = a[0];
+      p.out[15] = 0.0;
+      __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}

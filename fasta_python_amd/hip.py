@@ -214,9 +214,10 @@ class HipContext:
         return self._scal.copy()
 
     def fused_supported(self):
+        """0 = no one-pass kernel for this operator, 1 = dense (speculative), 2 = stencil (replaces both launches)."""
         yes = _i32(0)
         self._call("fh_fused_supported", C.byref(yes))
-        return bool(yes.value)
+        return int(yes.value)
 
     def step(self, tau):
         """One-pass K-fwd + K-adj (no acceleration).  Raises if the bounded spins timed out."""

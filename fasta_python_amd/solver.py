@@ -160,9 +160,13 @@ class FBSolver:
         if self.func:                                                   # :149-151
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
-        self.use_fused = (self.fused_opt is not False) and (not self.accelerate) and c.fused_supported()
+        kind = c.fused_supported() if (self.fused_opt is not False and not self.accelerate) else 0
+        self.use_fused = kind != 0
+        # dense: speculative (a rejected step wastes the A^T half, so back off after backtracks);
+        # stencil: the one-pass kernel costs no more than K-fwd alone, so it also serves the backtracking retries
+        self.fused_always = kind == 2
         if self.fused_opt is True and not self.use_fused:
-            raise ValueError("fused=True needs a dense operator with n = 4096*{1,2,4,8,16} and accelerate=False")
+            raise ValueError("fused=True needs accelerate=False and a stencil operator or a dense one with n = 4096*{1,2,4,8,16}")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
         self.alpha1 = 1.0                                               # :157
@@ -182,7 +186,7 @@ class FBSolver:
 
         fval = self._fval
         a = None
-        if self.use_fused and self._spec_cooldown == 0:
+        if self.use_fused and (self.fused_always or self._spec_cooldown == 0):
             try:
                 s = c.step(tau)                                         # one pass over A: K-fwd and K-adj together
                 a = s
@@ -201,10 +205,14 @@ class FBSolver:
             while (f1 - (M + s[hip.S_DXG0] + np.sqrt(s[hip.S_DX2]) ** 2 / (2 * tau)) > EPSILON
                    and bt < self.max_backtracks):
                 tau *= self.stepsize_shrink
-                s = c.fwd(tau)                                          # :207-213  (K-fwd again)
+                if self.use_fused and self.fused_always:
+                    s = a = c.step(tau)                                 # stencil: one-pass kernel again
+                    self.fused_steps += 1
+                else:
+                    s = c.fwd(tau)                                      # :207-213  (K-fwd again)
+                    a = None                                            # a speculative K-adj (if any) is void
                 f1 = fval(s[hip.S_FSQ])
                 bt += 1
-                a = None                                                # a speculative K-adj (if any) is void
             self.total_backtracks += bt
             if bt:
                 self._spec_cooldown = 8

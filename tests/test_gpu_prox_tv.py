@@ -133,3 +133,59 @@ def test_tv_full_size_adjointness_8192():
         assert Z[-1, -1] == (Y[0, -1, 0] - Y[-1, -1, 0]) + (Y[-1, 0, 1] - Y[-1, -1, 1])
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130)])
+def test_one_pass_tv_step_equals_two_launch_step(H_, W_):
+    """fh_step on the stencil operator (k_fused_tv_step) against fh_fwd + fh_adj on the same state."""
+    rng = np.random.RandomState(H_ * 7 + W_)
+    M = rng.randn(H_, W_)
+    Y0 = rng.randn(H_, W_, 2) * 0.8
+    tau = 0.11
+    op = fa.GradDivMap((H_, W_))
+    try:
+        c = op.ctx
+        assert c.fused_supported() == 2
+
+        def fresh():
+            c.set_loss_lsq(M)
+            c.set_prox(hip.PROX_TVBALL)
+            c.set_vector(hip.VEC_X0, Y0)
+            c.init()
+        fresh()
+        s = c.fwd(tau)
+        a = c.adj(tau)
+        xp_ref = c.get_vector(hip.VEC_XPROX, Y0.size)
+        z_ref = c.get_vector(hip.VEC_Z, M.size)
+        fresh()
+        f = c.step(tau)
+        assert np.array_equal(c.get_vector(hip.VEC_XPROX, Y0.size), xp_ref)
+        assert np.array_equal(c.get_vector(hip.VEC_Z, M.size), z_ref)
+        for k in (hip.S_FSQ, hip.S_DXG0, hip.S_DX2, hip.S_XH2, hip.S_G02):
+            np.testing.assert_allclose(f[k], s[k], rtol=1e-12, atol=1e-300, err_msg=f"fwd scalar {k}")
+        for k in (hip.S_DXDG, hip.S_DG2):
+            np.testing.assert_allclose(f[k], a[k], rtol=1e-11, atol=1e-300, err_msg=f"adj scalar {k}")
+    finally:
+        op.close()
+
+
+def test_tv_solve_identical_with_and_without_the_one_pass_kernel():
+    np.random.seed(9)
+    P = pr.tv_denoising(H=96, W=130, square=16)
+    M, mu = P.data["M"], P.data["mu"]
+    op = fa.GradDivMap(M.shape)
+    try:
+        ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        opts = dict(max_iters=80, tolerance=1e-5, evaluate_objective=True)
+        out = []
+        for fused in (True, False):
+            np.random.seed(2)
+            out.append(fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, fused=fused, **opts))
+    finally:
+        op.close()
+    a, b = out
+    assert a.iteration_count == b.iteration_count and a.backtracks == b.backtracks and a.backtracks > 0
+    k = a.iteration_count
+    np.testing.assert_allclose(a.residuals[:k], b.residuals[:k], rtol=1e-7)
+    np.testing.assert_allclose(a.objectives[:k + 1], b.objectives[:k + 1], rtol=1e-9)
+    np.testing.assert_allclose(a.solution, b.solution, rtol=1e-6, atol=1e-10)
