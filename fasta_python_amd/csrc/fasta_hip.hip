@@ -106,13 +106,15 @@ struct fh_ctx {
   uint64_t H = 0, W = 0;
   double* A = nullptr;
   // n-side
-  double* X[2] = {nullptr, nullptr};   // x0 / x1 (ping-pong)
+  // iterate pool: X[xi] = x0, X[ti] = where the next x1 lands, X[bi] = best-quality iterate (may alias X[xi]):
+  // the best iterate is tracked by index, never copied (a 1 GiB copy per improving iteration at 8192^2 TV)
+  double* X[3] = {nullptr, nullptr, nullptr};
+  int xi = 0, ti = 1, bi = 0;
   double* P[2] = {nullptr, nullptr};   // prox outputs: x_accel1 / x_accel0
   double* G[2] = {nullptr, nullptr};   // g0 / g1
   double* xhat = nullptr;
-  double* best = nullptr;
   double* T[4] = {nullptr, nullptr, nullptr, nullptr};
-  int xc = 0, pc = 0, gc = 0, zc = 0;
+  int pc = 0, gc = 0, zc = 0;
   bool last_accel = false;
   // m-side
   double* b = nullptr;
@@ -171,8 +173,9 @@ static int use_device(fh_ctx* c) {
 static void free_operator(fh_ctx* c) {
   auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   fr(c->A);
-  for (int i = 0; i < 2; ++i) { fr(c->X[i]); fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
-  fr(c->xhat); fr(c->best); fr(c->b); fr(c->zt); fr(c->ZX[0]); fr(c->ZX[1]);
+  for (int i = 0; i < 2; ++i) { fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
+  for (int i = 0; i < 3; ++i) fr(c->X[i]);
+  fr(c->xhat); fr(c->b); fr(c->zt); fr(c->ZX[0]); fr(c->ZX[1]);
   for (int i = 0; i < 4; ++i) fr(c->T[i]);
   fr(c->ws); c->ws_bytes = 0;
   c->op = OP_NONE; c->has_b = false;
@@ -187,18 +190,18 @@ static int alloc_zero(fh_ctx* c, double** p, uint64_t elems) {
 static int alloc_vectors(fh_ctx* c) {
   // +16 slack doubles on the n-side so sharded runs can append scalars to the all-reduce buffer
   for (int i = 0; i < 2; ++i) {
-    FH_TRY(alloc_zero(c, &c->X[i], c->nv + 16));
     FH_TRY(alloc_zero(c, &c->P[i], c->nv + 16));
     FH_TRY(alloc_zero(c, &c->G[i], c->nv + 16));
     FH_TRY(alloc_zero(c, &c->Z[i], c->mv + 16));
   }
   FH_TRY(alloc_zero(c, &c->xhat, c->nv + 16));
-  FH_TRY(alloc_zero(c, &c->best, c->nv + 16));
+  for (int i = 0; i < 3; ++i) FH_TRY(alloc_zero(c, &c->X[i], c->nv + 16));
   for (int i = 0; i < 4; ++i) FH_TRY(alloc_zero(c, &c->T[i], c->nv + 16));
   FH_TRY(alloc_zero(c, &c->b, c->mv + 16));
   FH_TRY(alloc_zero(c, &c->zt, c->mv + 16));
   if (c->op_pending_stencil) { FH_TRY(alloc_zero(c, &c->ZX[0], c->mv + 16)); FH_TRY(alloc_zero(c, &c->ZX[1], c->mv + 16)); }
-  c->xc = c->pc = c->gc = c->zc = c->zxc = 0;
+  c->pc = c->gc = c->zc = c->zxc = 0;
+  c->xi = 0; c->ti = 1; c->bi = 0;
   c->zcur = nullptr;
   return 0;
 }
@@ -452,13 +455,13 @@ static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
   // the stencil path never materialises the gradient or xhat (fh_tv.h): those ids are not addressable there
   if (c->op == OP_STENCIL && (which == FH_VEC_G0 || which == FH_VEC_G1 || which == FH_VEC_XHAT)) return nullptr;
   switch (which) {
-    case FH_VEC_X0: return c->X[c->xc];
+    case FH_VEC_X0: return c->X[c->xi];
     case FH_VEC_G0: return c->G[c->gc];
     case FH_VEC_XHAT: return c->xhat;
     case FH_VEC_XPROX: return c->P[c->pc ^ 1];
-    case FH_VEC_X1: return acc ? c->X[c->xc ^ 1] : c->P[c->pc ^ 1];
+    case FH_VEC_X1: return acc ? c->X[c->ti] : c->P[c->pc ^ 1];
     case FH_VEC_G1: return c->G[c->gc ^ 1];
-    case FH_VEC_BEST: return c->best;
+    case FH_VEC_BEST: return c->X[c->bi];
     case FH_VEC_B: *len = c->m; return c->b;
     case FH_VEC_Z: *len = c->m; return c->Z[c->zc ^ 1];
     case FH_VEC_T0: case FH_VEC_T1: case FH_VEC_T2: case FH_VEC_T3: return c->T[which - FH_VEC_T0];
@@ -651,7 +654,7 @@ static int launch_gterms(fh_ctx* c, const double* x) {
 static int launch_level_search(fh_ctx* c, double tau) {
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "LINF / L1BALL prox need the dense operator");
   const double radius = c->prox_kind == FH_PROX_L1BALL ? c->mu : tau * c->mu;
-  const double* x0 = c->X[c->xc];
+  const double* x0 = c->X[c->xi];
   const double* g0 = c->G[c->gc];
   double* out = c->dscal + FH_NSCALARS;
   const uint32_t n = (uint32_t)c->n;
@@ -784,7 +787,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, int mode, double* g1) {
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.nteams = (uint32_t)(c->ncu / FT_TEAM);
   p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
-  p.x0 = c->X[c->xc]; p.g0 = c->G[c->gc]; p.xhat = c->xhat; p.xp = c->P[c->pc ^ 1];
+  p.x0 = c->X[c->xi]; p.g0 = c->G[c->gc]; p.xhat = c->xhat; p.xp = c->P[c->pc ^ 1];
   p.b = c->b; p.z = c->Z[c->zc ^ 1]; p.tau = tau; p.loss = c->loss_kind; p.mode = mode;
   p.px = make_prox(c, tau);
   const unsigned grid = p.nteams * FT_TEAM;
@@ -850,7 +853,7 @@ static int check_ready(fh_ctx* c, bool need_b) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_init(fh_ctx* c, double* scalars) {
   FH_TRY(check_ready(c, true));
-  double* x0 = c->X[c->xc];
+  double* x0 = c->X[c->xi];
   // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
   FH_TRY(op_fwd(c, 1, 0.0, x0, nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
@@ -862,7 +865,8 @@ extern "C" int fh_init(fh_ctx* c, double* scalars) {
   }
   // x_accel1 := x0, best := x0 ; g(x0) terms for objective_hist[0] (:143) come from the host wrapper via FH_VEC ops
   HIP_TRY(hipMemcpyAsync(c->P[c->pc], x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->best, x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  c->bi = c->xi;                         // best iterate := x0 (fasta/__init__.py:167), by reference
+  for (int k = 0; k < 3; ++k) if (k != c->xi) { c->ti = k; break; }
   c->last_accel = false;
   FH_TRY(launch_gterms(c, x0));
   return fetch_scalars(c, scalars);
@@ -900,7 +904,7 @@ extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
 extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  FH_TRY(op_fwd(c, 0, tau, c->X[c->xc], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
+  FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
   return fetch_scalars(c, scalars);
 }
@@ -910,8 +914,8 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
   AdjIO io;
   io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
   io.mode = 0; io.tau = tau;
-  io.x0 = c->X[c->xc]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-  io.x1 = c->X[c->xc ^ 1]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
+  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
   c->last_accel = accel != 0;
   FH_TRY(op_adj(c, io));
   return fetch_scalars(c, scalars);
@@ -933,7 +937,7 @@ static int launch_fused_tv(fh_ctx* c, double tau) {
   p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
   p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
   p.strip_groups = ((p.W + TVF_OWN - 1) / TVF_OWN + 3) / 4;
-  p.x0 = c->X[c->xc]; p.xacc0 = nullptr; p.xp = c->P[c->pc ^ 1]; p.zc = c->zcur; p.b = c->b; p.zn = c->Z[c->zc ^ 1];
+  p.x0 = c->X[c->xi]; p.xacc0 = nullptr; p.xp = c->P[c->pc ^ 1]; p.zc = c->zcur; p.b = c->b; p.zn = c->Z[c->zc ^ 1];
   p.tau = tau;
   const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
@@ -976,8 +980,8 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
     t_end(c, FH_K_COMM);
     AdjIO io;
     io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 0; io.coef = 0.0; io.mode = 0; io.tau = tau;
-    io.x0 = c->X[c->xc]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-    io.x1 = c->X[c->xc ^ 1]; io.g1 = g1; io.g0 = c->G[c->gc];
+    io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+    io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
     FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ));
   }
   return fetch_scalars(c, scalars);
@@ -986,20 +990,21 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
 extern "C" int fh_commit(fh_ctx* c, int save_best) {
   FH_TRY(check_ready(c, false));
   if (c->last_accel) {
-    c->xc ^= 1;   // x0 <- extrapolated x1 (X ping-pong)
-    c->pc ^= 1;   // x_accel0 <- this iteration's prox output (P ping-pong)
+    c->pc ^= 1;                                   // x_accel0 <- this iteration's prox output (P ping-pong)
   } else {
-    // x1 is the prox output itself: adopt its buffer as x0; the old x0 buffer becomes the next prox target
-    std::swap(c->X[c->xc], c->P[c->pc ^ 1]);
+    // x1 is the prox output itself: adopt its buffer into the pool slot ti; the slot's old buffer becomes the
+    // next prox target
+    std::swap(c->X[c->ti], c->P[c->pc ^ 1]);
   }
+  c->xi = c->ti;                                  // x0 <- x1
+  if (save_best) c->bi = c->xi;                   // best iterate by reference (fasta/__init__.py:298-300)
+  for (int k = 0; k < 3; ++k) if (k != c->xi && k != c->bi) { c->ti = k; break; }   // a slot that is neither x0 nor best
   c->zc ^= 1;     // z_accel0 <- z1
   c->gc ^= 1;     // g0 <- g1
   if (c->op == OP_STENCIL) {
     if (c->last_accel) { c->zxc ^= 1; c->zcur = c->ZX[c->zxc]; }   // residual source = extrapolated z'
     else c->zcur = c->Z[c->zc];                                      // residual source = z1 itself
   }
-  if (save_best)
-    HIP_TRY(hipMemcpyAsync(c->best, c->X[c->xc], c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 
