@@ -128,13 +128,12 @@ def pmc_traffic(kernel_substr):
     (profiles/*_pmc_summary.json, produced by scripts/profile_bench.sh + summarize_profile.py)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        data = json.load(fh)
-    for name, rec in data["kernels"].items():
-        if kernel_substr in name:
-            return rec["traffic_bytes"], os.path.basename(files[-1])
+    for path in reversed(files):                       # newest summary that profiled this kernel
+        with open(path) as fh:
+            data = json.load(fh)
+        for name, rec in data["kernels"].items():
+            if kernel_substr in name:
+                return rec["traffic_bytes"], os.path.basename(path)
     return None, None
 
 
@@ -186,7 +185,10 @@ def run_tv(args, grp):
         "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), adaptive FBS with backtracking",
                    "backtracks_in_timed_steps": solver.total_backtracks - bt0, "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("k_fused_tv_step" if "fused" in dom else ("k_fwd_tv_step" if "fwd" in dom else "k_adj_tv_step"))[0]
+                     if side == 8192 else None,
+                     "kernel": dom,
                      "avg_launch_ms": dms / dcnt, "algorithmic_bytes_per_launch": dbytes,
                      "note": "priced at the materialised-vector model of SURVEY.md 8(d) (64*P / 72*P); this build never "
                              "materialises the gradient: the two step kernels move 56*P each, the one-pass kernel ~60*P for both (fh_tv.h)",
