@@ -28,7 +28,6 @@
 
 #define FT_TEAM 8
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
-#define FT_COMM_SLEEP 6                              // x64 cycles between polls of the dedicated comm wave
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock
 
 struct FusedP {
@@ -262,248 +261,6 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = a[0];
       p.out[S_ALPHA] = level;
       p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
-    }
-  }
-}
-
-// =================================================================================================
-// Variant with a dedicated COMM wave: wave 0 only publishes/polls, waves 1..3 own all matrix traffic.
-// `vmcnt` retires in order, so a wave that polls with vector loads first waits for every row load it has in
-// flight -- with the polling done by a compute wave the pipeline degenerates to one row in flight per CU
-// (measured: 5.7 TB/s moved).  Here the polling wave has nothing else outstanding, so two rows stay in
-// flight through every exchange.  The member's 256*PPT pieces form NJ = 4*PPT lane-columns of 64 pieces
-// (piece q = j*64 + lane); the three compute waves take contiguous j ranges (21/21/22 of 64 at PPT = 16).
-// The prox'd x slice sits in LDS (64 KiB at PPT = 16) to keep the per-lane registers at g1 slice + 3 buffers.
-// =================================================================================================
-template <int PPT, int NT, int KIND>
-__global__ __launch_bounds__(FH_WG, 1) void k_fused3_dense(const FusedP p) {
-  constexpr int NJ = 4 * PPT;
-  constexpr int MAXJ = (NJ + 2) / 3;
-  __shared__ __attribute__((aligned(16))) d2 s_xq[FH_WG * PPT];
-  __shared__ __attribute__((aligned(16))) double s_part[4];
-  __shared__ __attribute__((aligned(16))) double s_bc[2];
-  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
-  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / FT_TEAM;
-  const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % FT_TEAM;
-  const uint32_t mbase = mem * (FH_WG * PPT);                    // first piece of this member
-  const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
-
-  // ---------------- n-side (all four waves): prox'd slice -> LDS; team 0 owns the outputs -----------------
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    const uint32_t q = tid + k * FH_WG;
-    const uint32_t c = mbase + q;
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-    const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
-    d2 xh, xp;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const bool valid = (2u * c + e) < p.n;
-      double xhe = fwd_point(x0v[e], g0v[e], p.tau);
-      double xpe = prox_scalar<KIND>(xhe, p.px, level);
-      if (!valid) { xhe = 0.0; xpe = 0.0; }
-      xh[e] = xhe; xp[e] = xpe;
-      if (valid && team == 0) {
-        const double dx = sub_nofma(xpe, x0v[e]);
-        const double dh = sub_nofma(xpe, xhe);
-        v[0] = fma(dx, g0v[e], v[0]);
-        v[1] = fma(dx, dx, v[1]);
-        v[2] = fma(dh, dh, v[2]);
-        v[3] = fma(g0v[e], g0v[e], v[3]);
-        v[4] += fabs(xpe);
-        v[5] = fmax(v[5], fabs(xpe));
-      }
-    }
-    s_xq[q] = xp;
-    if (team == 0) {
-      store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
-      store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
-    }
-  }
-  __syncthreads();
-
-  // ---------------- rows ------------------------------------------------------------------------------------
-  const bool comm = wave == 0;
-  const uint32_t cw = comm ? 1u : wave;                          // compute-wave index 1..3 (comm wave: dummy)
-  const uint32_t jb = ((cw - 1u) * NJ) / 3u, je = (cw * NJ) / 3u;
-  const uint32_t nj = comm ? 0u : je - jb;                       // lane-columns of this wave (wave-uniform)
-  const uint32_t q0 = jb * 64u + lane;                           // first piece of this lane within the member
-  const uint32_t r_begin = min(team * p.rows_per_team, p.mp);
-  const uint32_t r_end = min(r_begin + p.rows_per_team, p.mp);
-  const d2* Abase = reinterpret_cast<const d2*>(p.A) + mbase + q0;
-  d2 ga[MAXJ];
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) ga[j] = (d2){0.0, 0.0};
-  double fs = 0.0;
-  bool dead = false;
-
-  // Branch-free hot loop: a wave with fewer than MAXJ lane-columns re-loads its last one (clamped offset) and
-  // gives the duplicate a zero weight in the dot product; its dummy accumulator is never stored.
-  uint32_t joff[MAXJ];
-  double jw[MAXJ];
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const bool real = (uint32_t)j < nj;
-    joff[j] = (real ? (uint32_t)j : (nj ? nj - 1u : 0u)) * 64u;
-    jw[j] = real ? 1.0 : 0.0;
-  }
-  auto load_row = [&](d2 (&buf)[MAXJ], uint32_t r) {
-    if (r < r_end && !comm) {
-      const d2* src = Abase + (uint64_t)r * p.ld2;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) buf[j] = load_stream<NT>(src + joff[j]);
-    }
-  };
-  auto process_row = [&](d2 (&buf)[MAXJ], uint32_t r) {          // r < r_end, uniform over the workgroup
-    if (!comm) {
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        const d2 xv = s_xq[q0 + joff[j]];
-        double pj = buf[j].x * xv.x;
-        pj = fma(buf[j].y, xv.y, pj);
-        part = fma(pj, jw[j], part);
-      }
-      part = wave_sum(part);
-      if (lane == 0) s_part[wave] = part;
-    }
-    __syncthreads();
-    if (comm) {
-      double* line = p.slots + (uint64_t)r * FT_TEAM;
-      if (lane == 0) store_partial(line + mem, (s_part[1] + s_part[2]) + s_part[3]);
-      double val = 0.0;
-      if (lane < FT_TEAM && !dead) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-          val = load_partial(line + lane);
-          if (!ft_is_sentinel(val)) break;
-          if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS ||
-              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val = 0.0;
-            dead = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(FT_COMM_SLEEP);
-        }
-      }
-      double zs = __shfl(val, 0, 64);
-#pragma unroll
-      for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
-      if (lane == 0) {
-        const double bi = p.b[r];
-        s_bc[0] = loss_grad(zs, bi, p.loss);
-        if (mem == 0) {
-          p.z[r] = zs;
-          if (r < p.m) fs += loss_term(zs, bi, p.loss);
-        }
-      }
-    }
-    __syncthreads();
-    if (!comm) {
-      const double rv = s_bc[0];
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        ga[j].x = fma(buf[j].x, rv, ga[j].x);
-        ga[j].y = fma(buf[j].y, rv, ga[j].y);
-      }
-    }
-  };
-
-  {
-    d2 b0[MAXJ], b1[MAXJ], b2[MAXJ];
-    load_row(b0, r_begin);
-    load_row(b1, r_begin + 1u);
-    for (uint32_t r = r_begin; r < r_end; r += 3u) {
-      load_row(b2, r + 2u);
-      process_row(b0, r);
-      load_row(b0, r + 3u);
-      if (r + 1u < r_end) process_row(b1, r + 1u);
-      load_row(b1, r + 4u);
-      if (r + 2u < r_end) process_row(b2, r + 2u);
-    }
-  }
-
-  // ---------------- publish slice partial, loss partial and (team 0) n-side partials ---------------------------
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j)
-    if ((uint32_t)j < nj)
-      store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + mbase + q0 + j * 64, ga[j]);
-  {
-    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], 0.0};
-    block_reduce<8>(w, s_scr, 6);
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + k, w[k]);
-    }
-  }
-
-  // ---------------- bounded grid barrier ---------------------------------------------------------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
-        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-
-  // ---------------- every workgroup finalises its share of the columns ----------------------------------------
-  AdjP e;
-  e.accel = 0; e.coef = 0.0; e.tau = p.tau;
-  double u[5] = {0, 0, 0, 0, 0};
-  const uint32_t share = (p.ld2 + gridDim.x - 1) / gridDim.x;
-  for (uint32_t t = tid; t < share; t += FH_WG) {
-    const uint32_t c = blockIdx.x * share + t;
-    if (c >= p.ld2) continue;
-    const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
-    d2 g = {0.0, 0.0};
-#pragma unroll 8
-    for (uint32_t s = 0; s < p.nteams; ++s) g += load_partial2(gp + (uint64_t)s * p.ld2);
-    reinterpret_cast<d2*>(p.g1)[c] = g;
-    if (p.mode == 0) {
-      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-      const d2 xpv = load_partial2(reinterpret_cast<const d2*>(p.xp) + c);
-      const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
-      bb_element(e, g.x, x0v.x, xpv.x, 0.0, xhv.x, 2u * c < p.n, u);
-      bb_element(e, g.y, x0v.y, xpv.y, 0.0, xhv.y, 2u * c + 1u < p.n, u);
-    }
-  }
-  block_reduce<5>(u, s_scr, 4);
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + 8 + k, u[k]);
-  }
-  if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
-  double w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const double q = load_partial(p.red + (uint64_t)i * 16 + k);
-      if (k == 6 || k == 12) w[k] = fmax(w[k], q); else w[k] += q;
-    }
-  }
-  {
-    double a[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], 0.0};
-    block_reduce<8>(a, s_scr, 6);
-    double bq[5] = {w[8], w[9], w[10], w[11], w[12]};
-    block_reduce<5>(bq, s_scr, 4);
-    if (tid == 0) {
-      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
-      p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = 0.0;
-      p.out[S_DXDG] = bq[0]; p.out[S_DG2] = bq[1]; p.out[S_XH2_ADJ] = bq[2]; p.out[S_GSUM_ADJ] = bq[3];
-      p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = a[0];
-      p.out[S_ALPHA] = level;
-      p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;
     }
   }
 }

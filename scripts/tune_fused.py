@@ -25,10 +25,10 @@ def timed(fn, kid, reps=6):
 
 
 for rnd in range(2):
-    for variant in (2, 10):
+    for variant in (2, 0):
         ctx.set_tuning(hip.TUNE_FUSED_VARIANT, variant)
         t = timed(lambda: ctx.step(0.2), hip.K_FUSED)
-        print(f"round {rnd} variant {variant} (defer={variant & 1} xcd={(variant >> 1) & 1} commwave={(variant >> 3) & 1}): "
+        print(f"round {rnd} variant {variant} (defer={variant & 1} xcd={(variant >> 1) & 1} prefetch_deferred={variant & 1}): "
               f"{t:7.3f} ms  moves {m * n * 8 / t / 1e6:6.0f} GB/s  algorithmic {2 * m * n * 8 / t / 1e6:6.0f} GB/s", flush=True)
 tf = timed(lambda: ctx.fwd(0.2), hip.K_FWD)
 ta = timed(lambda: ctx.adj(0.2), hip.K_ADJ)
