@@ -1,0 +1,172 @@
+"""NumPy stand-in for `fasta_python_amd.hip.HipContext` -- TEST INFRASTRUCTURE.
+
+It implements the C-ABI contract of include/fasta_hip.h (the scalar block of fh_init / fh_fwd / fh_adj /
+fh_step, the vector ids, fh_commit's rotation and best-iterate rule) with the oracle's NumPy operators, so the
+product's HOST logic (fasta_python_amd/solver.py: backtracking, restart, Barzilai-Borwein, the speculative
+one-pass path, histories, best iterate) can be exercised by the CPU test tier against the reference-captured
+golden fixtures.  It is never imported by the product."""
+import numpy as np
+
+from fasta_python_amd import hip
+from fasta_python_amd.linalg import LinearMap, _DeviceMap
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+
+class FakeContext:
+    def __init__(self, fwd, adj, n_shape, m_shape, fused_kind=0):
+        self.fwd_op, self.adj_op = fwd, adj
+        self.n_shape, self.m_shape = tuple(n_shape), tuple(m_shape)
+        self.fused_kind = fused_kind
+        self.calls = {"fwd": 0, "adj": 0, "step": 0}
+        self.vec = {}
+        self.loss = "lsq"
+        self.prox_kind, self.mu, self.lo, self.hi = hip.PROX_IDENTITY, 0.0, 0.0, 0.0
+
+    # ---- problem data ----
+    def shape(self):
+        return int(np.prod(self.m_shape)), int(np.prod(self.n_shape))
+
+    def set_loss_lsq(self, b):
+        self.b, self.loss = np.asarray(b, dtype=float).reshape(self.m_shape), "lsq"
+
+    def set_loss_logistic(self, b):
+        self.b, self.loss = np.asarray(b, dtype=float).reshape(self.m_shape), "logistic"
+
+    def set_prox(self, kind, mu=0.0, lo=0.0, hi=0.0):
+        self.prox_kind, self.mu, self.lo, self.hi = kind, mu, lo, hi
+
+    def set_vector(self, which, v):
+        self.vec[which] = np.array(v, dtype=float).reshape(self.n_shape)
+
+    def get_vector(self, which, length):
+        if which == hip.VEC_BEST:
+            return self.best.ravel().copy()
+        if which == hip.VEC_X0:
+            return self.x0.ravel().copy()
+        return self.vec[which].ravel().copy()
+
+    # ---- maths ----
+    def _f_sum(self, z):
+        if self.loss == "logistic":
+            return float(np.sum(np.log(1 + np.exp(z)) - (self.b == 1) * z))
+        return float(np.sum((z - self.b) ** 2))
+
+    def _gradf(self, z):
+        if self.loss == "logistic":
+            return -self.b / (1 + np.exp(self.b * z))
+        return z - self.b
+
+    def _prox(self, x, tau):
+        k = self.prox_kind
+        if k == hip.PROX_SHRINK:
+            return fo.shrink(x, tau * self.mu)
+        if k == hip.PROX_NONNEG:
+            return np.maximum(x, 0)
+        if k == hip.PROX_LINF:
+            return fo.prox_linf(x, tau * self.mu)
+        if k == hip.PROX_L1BALL:
+            return fo.project_l1(x, self.mu)
+        if k == hip.PROX_TVBALL:
+            return fo.tv_dual_ball(x)
+        if k == hip.PROX_BOX:
+            return np.clip(x, self.lo, self.hi)
+        return x
+
+    @staticmethod
+    def _gterms(x, s):
+        s[hip.S_GSUM] = np.abs(x).sum()
+        s[hip.S_GMAX] = np.abs(x).max(initial=0.0)
+
+    # ---- solver steps ----
+    def init(self):
+        self.x0 = self.vec[hip.VEC_X0]
+        self.z_acc = self.fwd_op(self.x0)
+        self.zcur = self.z_acc
+        self.g0 = self.adj_op(self._gradf(self.z_acc))
+        self.xacc = self.x0
+        self.best = self.x0
+        s = np.zeros(hip.NSCALARS)
+        s[hip.S_FSQ] = self._f_sum(self.z_acc)
+        self._gterms(self.x0, s)
+        return s
+
+    def gradient_at(self, src, dst):
+        self.vec[dst] = self.adj_op(self._gradf(self.fwd_op(self.vec[src])))
+
+    def diff_norm(self, a, b):
+        return float(np.linalg.norm((self.vec[a] - self.vec[b]).ravel()))
+
+    def fwd(self, tau):
+        self.calls["fwd"] += 1
+        x0, g0 = self.x0, self.g0
+        self.xhat = x0 - tau * g0
+        self.xp = self._prox(self.xhat, tau)
+        self.z1 = self.fwd_op(self.xp)
+        dx = (self.xp - x0).ravel()
+        s = np.zeros(hip.NSCALARS)
+        s[hip.S_FSQ] = self._f_sum(self.z1)
+        s[hip.S_DXG0] = dx @ g0.ravel()
+        s[hip.S_DX2] = dx @ dx
+        s[hip.S_XH2] = np.sum((self.xp - self.xhat) ** 2)
+        s[hip.S_G02] = np.sum(g0 ** 2)
+        s[hip.S_RDOT] = (x0 - self.xp).ravel() @ (self.xp - self.xacc).ravel()
+        self._gterms(self.xp, s)
+        self._fwd_scalars = s
+        return s.copy()
+
+    def adj(self, tau, accel=False, coef=0.0):
+        self.calls["adj"] += 1
+        z, x1 = self.z1, self.xp
+        if accel:
+            z = z + coef * (z - self.z_acc)
+            x1 = x1 + coef * (x1 - self.xacc)
+        self.accel, self.x1, self.z_ext = bool(accel), x1, z
+        self.g1 = self.adj_op(self._gradf(z))
+        dg = self.g1 + (self.xhat - self.x0) / tau
+        dx = (self.xp - self.x0).ravel()
+        s = self._fwd_scalars.copy()
+        s[hip.S_DXDG] = dx @ dg.ravel()
+        s[hip.S_DG2] = np.sum(dg ** 2)
+        s[hip.S_FSQ_ADJ] = self._f_sum(z)
+        s[hip.S_XH2_ADJ] = np.sum((x1 - self.xhat) ** 2)
+        s[hip.S_GSUM_ADJ] = np.abs(x1).sum()
+        s[hip.S_GMAX_ADJ] = np.abs(x1).max(initial=0.0)
+        return s
+
+    def fused_supported(self):
+        return self.fused_kind
+
+    def step(self, tau):
+        self.calls["step"] += 1
+        self.fwd(tau)
+        self.calls["fwd"] -= 1
+        s = self.adj(tau)
+        self.calls["adj"] -= 1
+        return s
+
+    def commit(self, save_best=False):
+        self.xacc, self.z_acc = self.xp, self.z1          # FISTA history (pre-extrapolation values)
+        self.x0, self.g0 = self.x1, self.g1
+        if save_best:
+            self.best = self.x1
+
+    def close(self):
+        pass
+
+
+class FakeDenseMap(_DeviceMap):
+    """Device-map look-alike over a host matrix (bypasses HipContext creation)."""
+
+    def __init__(self, A, fused_kind=0):
+        A = np.asarray(A, dtype=float)
+        self.matrix = A
+        self.ctx = FakeContext(lambda x: A @ x, lambda y: A.T @ y, (A.shape[1],), (A.shape[0],), fused_kind)
+        LinearMap.__init__(self, self.ctx.fwd_op, self.ctx.adj_op, (A.shape[1],), (A.shape[0],))
+
+
+class FakeStencilMap(_DeviceMap):
+    def __init__(self, image_shape, fused_kind=2):
+        H, W = image_shape
+        self.ctx = FakeContext(pr.div, pr.grad, (H, W, 2), (H, W), fused_kind)
+        LinearMap.__init__(self, pr.div, pr.grad, (H, W, 2), (H, W))

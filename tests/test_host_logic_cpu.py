@@ -1,0 +1,105 @@
+"""CPU tier for the product's HOST logic: fasta_python_amd.solver driven through a NumPy stand-in for the
+device context (tests/fake_ctx.py) on the reference-captured golden fixtures -- backtracking, FISTA restart,
+Barzilai-Borwein, stop rules, histories, best iterate, and the speculative one-pass path with its fallback."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from fasta_python_amd import stopping as fstop
+from tests import helpers as H
+from tests.fake_ctx import FakeDenseMap, FakeStencilMap
+from tests.gpu_util import TAGS
+
+CASES = [n for n in H.golden_cases() if not n.startswith("c1_")]
+
+
+def _run(name, fused):
+    meta, z = H.load_case(name)
+    data = H.case_data(meta, z)
+    kind = meta["kind"]
+    if kind == "tv":
+        A = FakeStencilMap(data["M"].shape, fused_kind=2 if fused else 0)
+        loss, x0 = fa.LeastSquares(data["M"] / float(data["mu"])), np.zeros(data["M"].shape + (2,))
+    else:
+        A = FakeDenseMap(data["A"], fused_kind=1 if fused else 0)
+        loss = fa.LogisticLoss(data["b"]) if kind == "logistic" else fa.LeastSquares(data["b"])
+        x0 = np.zeros(data["A"].shape[1])
+    reg = TAGS[kind](data)
+    o = H.resolve_options(meta["options"], fstop)
+    g, proxg = (None, None) if o.pop("g_none", False) else (reg.g, reg.prox)
+    np.random.seed(meta["solver_seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, fused="auto", **o)
+    return meta, z, c, A.ctx
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", CASES)
+def test_driver_reproduces_reference_run(name, fused):
+    meta, z, c, ctx = _run(name, fused)
+    long_chaotic = int(z["backtracks"]) > 50                       # rounding is amplified there
+    if not long_chaotic:
+        assert c.iteration_count == int(z["iteration_count"])
+        assert c.backtracks == int(z["backtracks"])
+    k = min(c.iteration_count, int(z["iteration_count"]), 25 if long_chaotic else 10 ** 9)
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(c, f)[:k], z[f][:k], rtol=1e-6, atol=1e-13, err_msg=f)
+    if "objectives" in z.files:
+        np.testing.assert_allclose(c.objectives[:k + 1], z["objectives"][:k + 1], rtol=1e-6)
+    if not long_chaotic:
+        np.testing.assert_allclose(c.solution, z["solution"], rtol=1e-5, atol=1e-9)
+        if "iterates" in z.files:
+            np.testing.assert_allclose(c.iterates[:k + 1], z["iterates"][:k + 1], rtol=1e-5, atol=1e-9)
+    accelerated = bool(meta["options"].get("accelerate", False))
+    if fused and not accelerated:
+        assert ctx.calls["step"] > 0                               # the one-pass path was taken ...
+        if meta["kind"] != "tv" and c.backtracks:
+            assert ctx.calls["fwd"] > 0 and ctx.calls["adj"] > 0   # ... and abandoned for the backtracking retries
+    else:
+        assert ctx.calls["step"] == 0
+
+
+def test_speculation_backs_off_after_a_backtrack():
+    meta, z, c, ctx = _run("sparse_ls_unnormalised_backtracks", True)
+    # 105 backtracks in 200 iterations: most iterations must have used the two-launch path
+    assert ctx.calls["step"] < c.iteration_count // 2
+
+
+def test_operand_recognition_errors_without_a_gpu():
+    A = FakeDenseMap(np.eye(4))
+    ls, reg = fa.LeastSquares(np.zeros(4)), fa.Shrink(0.1)
+    other = fa.Shrink(0.2)
+    with pytest.raises(TypeError):
+        fa.fasta(A, lambda z: 0.0, ls.gradf, reg.g, reg.prox, np.zeros(4), verbose=False)
+    with pytest.raises(TypeError):
+        fa.fasta(A, ls.f, ls.gradf, other.g, reg.prox, np.zeros(4), verbose=False)      # g and proxg from different tags
+    with pytest.raises(TypeError):
+        fa.fasta(A, ls.f, fa.LeastSquares(np.zeros(4)).gradf, reg.g, reg.prox, np.zeros(4), verbose=False)
+    with pytest.raises(AssertionError):
+        fa.fasta(A, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5), verbose=False)
+    with pytest.raises(TypeError):
+        fa.fasta(A, ls.f, ls.gradf, reg.g, reg.prox, verbose=False)                     # wrong arity
+    with pytest.raises(ValueError):
+        fa.fasta(FakeDenseMap(np.eye(4), fused_kind=0), ls.f, ls.gradf, reg.g, reg.prox, np.zeros(4), verbose=False, fused=True)
+
+
+def test_linear_map_algebra_on_the_host():
+    """LinearMap composition / scaling / sums (fasta/linalg.py:71-136) stay host-side callables."""
+    rng = np.random.RandomState(0)
+    M, N = rng.randn(4, 4), rng.randn(4, 4)
+    A, B = FakeDenseMap(M), FakeDenseMap(N)
+    x = rng.randn(4)
+    np.testing.assert_allclose((A @ B)(x), M @ (N @ x))
+    np.testing.assert_allclose((A @ B).H(x), N.T @ (M.T @ x))
+    np.testing.assert_allclose((2.5 * A)(x), 2.5 * (M @ x))
+    np.testing.assert_allclose((A - B)(x), (M - N) @ x)
+    np.testing.assert_allclose((-A).H(x), -(M.T @ x))
+    np.testing.assert_allclose((A ** 3)(x), M @ (M @ (M @ x)))
+    assert A.is_operator and fa.LinearMap.identity((3,))(np.ones(3)).sum() == 3
+    L = fa.LinearOperator(lambda v: 2 * v, lambda v: 2 * v, (5,))       # 3-argument legacy form
+    assert L.Vshape == L.Wshape == (5,)
+    with pytest.raises(AssertionError):
+        A(np.zeros(5))
