@@ -923,9 +923,13 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
 
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
-  // 1 = dense one-pass kernel (speculative: a rejected step costs a wasted A^T half), 2 = stencil one-pass kernel
-  // (costs no more than K-fwd alone, so it simply replaces both launches), 0 = unsupported
-  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (fused_ppt(c) ? 1 : 0);
+  // 0 = unsupported; 1 = dense one-pass kernel, recommended (speculative: a rejected step wastes the A^T half);
+  // 2 = stencil one-pass kernel (costs no more than K-fwd alone: it simply replaces both launches);
+  // 3 = dense one-pass kernel available but NOT recommended: the per-row team hand-off (~0.5-3 us) only pays once a
+  //     member's piece of a row streams for longer than that, i.e. n >= 32768 (profiles/r01c_fused_vs_two.txt:
+  //     32768^2 492 vs 403 it/s, 16384^2 1198 vs 1446 it/s)
+  const int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
+  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt >= 8 ? 1 : (ppt ? 3 : 0));
   return 0;
 }
 

@@ -214,7 +214,8 @@ class HipContext:
         return self._scal.copy()
 
     def fused_supported(self):
-        """0 = no one-pass kernel for this operator, 1 = dense (speculative), 2 = stencil (replaces both launches)."""
+        """0 = none; 1 = dense one-pass kernel, recommended; 3 = dense, available but not recommended (n < 32768);
+        2 = stencil (one sweep replaces both launches)."""
         yes = _i32(0)
         self._call("fh_fused_supported", C.byref(yes))
         return int(yes.value)

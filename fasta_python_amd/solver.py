@@ -161,6 +161,8 @@ class FBSolver:
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
         kind = c.fused_supported() if (self.fused_opt is not False and not self.accelerate) else 0
+        if kind == 3 and self.fused_opt is not True:        # available but slower than two launches at this size
+            kind = 0
         self.use_fused = kind != 0
         # dense: speculative (a rejected step wastes the A^T half, so back off after backtracks);
         # stencil: the one-pass kernel costs no more than K-fwd alone, so it also serves the backtracking retries
