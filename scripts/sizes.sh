@@ -6,6 +6,6 @@ for s in "512 1024" "2048 2048" "4096 4096" "8192 8192" "16384 16384" "32768 327
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 pk=d['roofline']['per_kernel']
-f=pk['fasta_fwd(k_fwd_dense)']; a=pk['fasta_adj(k_adj_dense)']
-print('%6d x %6d  %8.0f it/s  %8.4f ms/step | fwd %7.4f ms %5.0f GB/s | adj %7.4f ms %5.0f GB/s' % (d['config']['m'], d['config']['n'], d['value'], d['ms_per_step'], f['avg_ms'], f['GB/s'], a['avg_ms'], a['GB/s']))"
+parts=' | '.join('%s %7.4f ms %5.0f GB/s' % (k.split('(')[1][:-1], v['avg_ms'], v['GB/s']) for k,v in pk.items() if v['launches'])
+print('%6d x %6d  %8.0f it/s  %8.4f ms/step | %s' % (d['config']['m'], d['config']['n'], d['value'], d['ms_per_step'], parts))"
 done
