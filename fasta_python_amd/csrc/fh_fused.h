@@ -48,7 +48,7 @@ struct FusedP {
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
   unsigned* err;         // set to 1 on a spin timeout
-  int variant;           // tuning bits: 1 = polling wave defers its prefetch, 2 = members of a team 32 blocks apart (one XCD), 4 = no s_sleep in the poll
+  int variant;           // bits: 1 = polling wave defers its prefetch, 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep in the poll, 64 = fault injection (tests)
   double* out;
 };
 
@@ -135,7 +135,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     __syncthreads();
     if (wave == 0) {
       double* line = p.slots + (uint64_t)r * FT_TEAM;
-      if (lane == 0) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+      // variant bit 64 = FAULT INJECTION for the test-suite: member 7 of team 0 never publishes its first row, so its
+      // team-mates must hit the wall-clock bound, raise p.err and let the whole grid drain (no hang)
+      const bool sabotage = (p.variant & 64) && team == 0 && mem == FT_TEAM - 1 && r == r_begin;
+      if (lane == 0 && !sabotage) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
       double val = 0.0;
       if (lane < FT_TEAM && !dead) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();

@@ -139,3 +139,37 @@ def test_fused_step_on_the_row_sharded_path_with_one_rank():
     np.testing.assert_allclose(got.residuals[:k], ref.residuals[:k], rtol=1e-9)
     np.testing.assert_allclose(got.objectives[:k + 1], ref.objectives[:k + 1], rtol=1e-9)
     np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-8, atol=1e-12)
+
+
+def test_lost_partial_times_out_instead_of_hanging_and_the_solver_falls_back():
+    """Safety net of the one-pass kernel: every spin is wall-clock bounded.  With a partial dot product deliberately
+    withheld (fault-injection bit), the launch must finish within about a second, report the timeout, and the
+    driver must carry on with the two-launch path and still produce the right solve."""
+    import time
+    rng = np.random.RandomState(2)
+    m, n = 96, 4096
+    A = rng.randn(m, n) / 40
+    b = rng.randn(m)
+    ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+    opts = dict(tolerance=1e-6, max_iters=12, evaluate_objective=True)
+    op = fa.DenseMatrixMap(A)
+    try:
+        np.random.seed(4)
+        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=False, **opts)
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 64)
+        c = _state(op, b, 0.02, np.zeros(n))
+        t0 = time.time()
+        with pytest.raises(hip.HipError):
+            c.step(0.3)
+        assert time.time() - t0 < 5.0
+        solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, fused=True, **opts)
+        np.random.seed(4)
+        with pytest.warns(UserWarning, match="one-pass kernel disabled"):
+            got = solver.setup().run()
+    finally:
+        op.close()
+    assert not solver.use_fused
+    assert got.iteration_count == ref.iteration_count
+    k = got.iteration_count
+    np.testing.assert_allclose(got.residuals[:k], ref.residuals[:k], rtol=1e-12)
+    np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
