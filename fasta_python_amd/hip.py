@@ -122,6 +122,7 @@ class HipContext:
         self.device = int(device)
         self._scal = np.zeros(NSCALARS)
         self._scal_p = self._scal.ctypes.data_as(_pd)
+        self.sharded = False            # True once a multi-rank communicator is attached (comm_init)
 
     # ---- lifetime ------------------------------------------------------------------------------
     def close(self):
@@ -246,9 +247,11 @@ class HipContext:
         assert len(unique_id) == UNIQUE_ID_BYTES
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._call("fh_comm_init", int(nranks), int(rank), buf)
+        self.sharded = True
 
     def comm_destroy(self):
         self._call("fh_comm_destroy")
+        self.sharded = False
 
     # ---- measurement ----------------------------------------------------------------------------
     def timing_enable(self, on=True):

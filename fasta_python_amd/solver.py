@@ -194,6 +194,8 @@ class FBSolver:
                 a = s
                 self.fused_steps += 1
             except hip.HipError as exc:                                 # bounded-spin timeout: never speculate again
+                if getattr(c, "sharded", False):
+                    raise       # ranks cannot fall back independently: their collective sequences would diverge
                 warnings.warn(f"fused one-pass kernel disabled: {exc}")
                 self.use_fused = False
                 s = c.fwd(tau)
