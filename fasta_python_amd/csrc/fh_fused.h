@@ -28,7 +28,13 @@
 
 #define FT_TEAM 8
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
-#define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock
+#define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock (grid barrier)
+#define FT_SPIN_POLLS 400000u                       // slot-poll budget: ~1.2 us per poll (sc1 load + s_sleep) => ~0.5 s
+
+// Workgroup barrier for LDS hand-offs inside the row loop.  `__syncthreads()` makes hipcc drain `vmcnt(0)` first,
+// which would land every prefetched row before each of the two per-row barriers (pipeline depth 0); this waits
+// for the LDS traffic only and leaves the row loads in flight.
+__device__ __forceinline__ void ft_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct FusedP {
   const double* A;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
     part = wave_sum(part);
     if (lane == 0) s_part[wave] = part;
-    __syncthreads();
+    ft_lds_barrier();
     if (wave == 0) {
       double* line = p.slots + (uint64_t)r * FT_TEAM;
       // variant bit 64 = FAULT INJECTION for the test-suite: member 7 of team 0 never publishes its first row, so its
@@ -141,17 +147,35 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       if (lane == 0 && !sabotage) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
       double val = 0.0;
       if (lane < FT_TEAM && !dead) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-          val = load_partial(line + lane);
-          if (!ft_is_sentinel(val)) break;
-          if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-              __builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
-            __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val = 0.0;
-            break;
-          }
-          if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
+        // The poll loop is written in asm on purpose: a C loop with loads inside this wave-0-only branch makes hipcc's
+        // waitcnt pass lose count at the join and emit `s_waitcnt vmcnt(0)` before every later use of the row buffers in
+        // ALL waves (measured: pipeline depth 0).  Hidden in asm, the compiler keeps exact counts for the row loads.
+        // Bounded by an iteration budget (~0.5 s with the sleep) instead of the clock to stay within 32-bit scalar ops.
+        const double* slot = line + lane;
+        const unsigned long long sent = ((unsigned long long)FT_SENTINEL_HI << 32) | FT_SENTINEL_HI;
+        unsigned long long tmp;
+        unsigned cnt = 0u, timed_out;
+        asm volatile(
+            "s_mov_b32 %[to], 0\n"
+            "1:\n\t"
+            "global_load_dwordx2 %[val], %[addr], off sc1\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "v_cmp_ne_u64 vcc, %[sent], %[val]\n\t"
+            "s_andn2_b64 %[tmp], exec, vcc\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            "s_sleep 1\n\t"
+            "s_add_u32 %[cnt], %[cnt], 1\n\t"
+            "s_cmp_lt_u32 %[cnt], %[max]\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "s_mov_b32 %[to], 1\n"
+            "2:\n"
+            : [val] "=&v"(val), [tmp] "=&s"(tmp), [cnt] "+s"(cnt), [to] "=&s"(timed_out)
+            : [addr] "v"(slot), [sent] "s"(sent), [max] "s"(FT_SPIN_POLLS)
+            : "vcc", "scc", "memory");
+        if (timed_out) {       // give up on the exchange for the rest of the launch (no p.err load in the loop:
+          dead = true;         // a C-level load there would drain every prefetched row each trip)
+          __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ft_is_sentinel(val)) val = 0.0;
         }
       }
       double zs = __shfl(val, 0, 64);
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
         if (mem == 0) p.z[r] = zs;
       }
     }
-    __syncthreads();
+    ft_lds_barrier();
     const double rv = s_bc[0];
     if (tid == 0 && mem == 0) fs += s_bc[1];
 #pragma unroll
@@ -183,7 +207,6 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       process_row(b0, r, b2, r + 2u);
       if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
       if (r + 2u < r_end) process_row(b2, r + 2u, b1, r + 4u);
-      if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
     }
   }
 
