@@ -62,7 +62,7 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-template <int PPT, int NT, int KIND>
+template <int PPT, int NT, int KIND, int DEFER>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i, loss term
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / FT_TEAM;
   const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % FT_TEAM;
-  const bool defer = (p.variant & 1) != 0;
   const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
   const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
 
@@ -112,6 +111,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // ---------------- rows of this team: one pass, three rotating register buffers ----------------------------
   const uint32_t r_begin = min(team * p.rows_per_team, p.mp);
   const uint32_t r_end = min(r_begin + p.rows_per_team, p.mp);
+  const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
   const d2* Abase = reinterpret_cast<const d2*>(p.A) + c0;
   d2 ga[PPT];
 #pragma unroll
@@ -119,17 +119,22 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   double fs = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
 
+  // Row loads are UNCONDITIONAL (callers clamp the row index to the team's last row; the two surplus reads per team are
+  // noise): hipcc's waitcnt pass merges the pending-load state of both sides of any branch by taking the SMALLER
+  // outstanding count, so a skipped prefetch on one path turns every later `s_waitcnt vmcnt(N)` into "wait for the
+  // newest loads too" -- i.e. no prefetch distance at all.
   auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
-    if (r < r_end) {
-      const d2* src = Abase + (uint64_t)r * p.ld2;
+    const d2* src = Abase + (uint64_t)r * p.ld2;
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + k * FH_WG);
-    }
+    for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + k * FH_WG);
   };
   // `vmcnt` retires in order: the polling wave (0) must not have a freshly issued row ahead of its poll loads, so it
   // issues the reload of the freed buffer AFTER the poll; waves 1-3 issue it up front (two rows in flight).
   auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
-    if (wave != 0 || !defer) load_row(nbuf, nr);
+    if (wave != 0 || !DEFER) load_row(nbuf, min(nr, r_last));
+    // b[r] through the scalar cache (constant address space => s_load, counted by lgkmcnt): as a vector load inside the
+    // lane-0 branch below it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
+    const double bi = ((const __attribute__((address_space(4))) double*)(uintptr_t)p.b)[r];
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -181,9 +186,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       double zs = __shfl(val, 0, 64);
 #pragma unroll
       for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
-      if (defer) load_row(nbuf, nr);                                // wave 0's deferred prefetch
+      if (DEFER) load_row(nbuf, min(nr, r_last));                   // wave 0's deferred prefetch
       if (lane == 0) {
-        const double bi = p.b[r];
         s_bc[0] = loss_grad(zs, bi, p.loss);
         s_bc[1] = r < p.m ? loss_term(zs, bi, p.loss) : 0.0;
         if (mem == 0) p.z[r] = zs;
@@ -199,14 +203,19 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   };
 
-  {
+  if (r_begin < r_end) {
     d2 b0[PPT], b1[PPT], b2[PPT];
     load_row(b0, r_begin);
-    load_row(b1, r_begin + 1u);
-    for (uint32_t r = r_begin; r < r_end; r += 3u) {
+    load_row(b1, min(r_begin + 1u, r_last));
+    uint32_t r = r_begin;
+    for (; r + 3u <= r_end; r += 3u) {              // branch-free body: exact vmcnt distances (two rows stay in flight)
+      process_row(b0, r, b2, r + 2u);
+      process_row(b1, r + 1u, b0, r + 3u);
+      process_row(b2, r + 2u, b1, r + 4u);
+    }
+    if (r < r_end) {
       process_row(b0, r, b2, r + 2u);
       if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
-      if (r + 2u < r_end) process_row(b2, r + 2u, b1, r + 4u);
     }
   }
 
