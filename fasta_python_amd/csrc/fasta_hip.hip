@@ -766,8 +766,7 @@ static int fused_ppt(fh_ctx* c) {          // pieces per lane, or 0 when the sha
 template <int PPT, int KIND>
 static void launch_fused_pk(fh_ctx* c, const FusedP& p, unsigned grid) {
   // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
-  if (p.variant & 1) k_fused_dense<PPT, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   // polling wave prefetches after its poll
-  else k_fused_dense<PPT, 1, KIND, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  k_fused_dense<PPT, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 template <int PPT>
 static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) {

@@ -54,7 +54,7 @@ struct FusedP {
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
   unsigned* err;         // set to 1 on a spin timeout
-  int variant;           // bits: 1 = polling wave defers its prefetch, 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep in the poll, 64 = fault injection (tests)
+  int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep in the poll, 64 = fault injection (tests)
   double* out;
 };
 
@@ -62,10 +62,10 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-template <int PPT, int NT, int KIND, int DEFER>
+template <int PPT, int NT, int KIND>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
-  __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i, loss term
+  __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // `vmcnt` retires in order: the polling wave (0) must not have a freshly issued row ahead of its poll loads, so it
   // issues the reload of the freed buffer AFTER the poll; waves 1-3 issue it up front (two rows in flight).
   auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
-    if (wave != 0 || !DEFER) load_row(nbuf, min(nr, r_last));
+    load_row(nbuf, min(nr, r_last));
     // b[r] through the scalar cache (constant address space => s_load, counted by lgkmcnt): as a vector load inside the
     // lane-0 branch below it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
     const double bi = ((const __attribute__((address_space(4))) double*)(uintptr_t)p.b)[r];
@@ -186,16 +186,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       double zs = __shfl(val, 0, 64);
 #pragma unroll
       for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
-      if (DEFER) load_row(nbuf, min(nr, r_last));                   // wave 0's deferred prefetch
       if (lane == 0) {
         s_bc[0] = loss_grad(zs, bi, p.loss);
-        s_bc[1] = r < p.m ? loss_term(zs, bi, p.loss) : 0.0;
-        if (mem == 0) p.z[r] = zs;
+        if (mem == 0) store_partial(p.z + r, zs);                    // read back below by other lanes of this workgroup
       }
     }
     ft_lds_barrier();
     const double rv = s_bc[0];
-    if (tid == 0 && mem == 0) fs += s_bc[1];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       ga[k].x = fma(buf[k].x, rv, ga[k].x);
@@ -217,6 +214,15 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       process_row(b0, r, b2, r + 2u);
       if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
     }
+  }
+
+  // ---------------- loss terms of this team's rows (member 0), off the exchange's critical path: keeping log/exp of the
+  // logistic objective out of the row loop also keeps their constants out of its (full) register budget
+  if (mem == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
+    for (uint32_t r = r_begin + tid; r < min(r_end, p.m); r += FH_WG) fs += loss_term(load_partial(p.z + r), bq[r], p.loss);
   }
 
   // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------

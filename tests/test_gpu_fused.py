@@ -57,6 +57,36 @@ def test_fused_step_equals_two_launch_step(m, n, variant):
         op.close()
 
 
+@pytest.mark.parametrize("m,n", [(1, 4096), (333, 4096), (2050, 8192)])
+def test_fused_step_with_the_logistic_loss_equals_two_launch_step(m, n):
+    """loss terms are summed after the row loop by each team's member 0; the gradient factor inside it."""
+    rng = np.random.RandomState(m)
+    A = rng.randn(m, n) / np.sqrt(n)
+    b = np.where(rng.rand(m) < 0.5, 1.0, -1.0)
+    x0, tau, mu = rng.randn(n) * 0.3, 0.7, 0.05
+    op = fa.DenseMatrixMap(A)
+    try:
+        def state():
+            c = op.ctx
+            c.set_loss_logistic(b); c.set_prox(hip.PROX_SHRINK, mu); c.set_vector(hip.VEC_X0, x0); c.init()
+            return c
+        c = state()
+        s, a = c.fwd(tau), c.adj(tau)
+        g1 = c.get_vector(hip.VEC_G1, n)
+        c = state()
+        f = c.step(tau)
+        np.testing.assert_allclose(f[hip.S_FSQ], s[hip.S_FSQ], rtol=1e-12)
+        for k in (hip.S_DXDG, hip.S_DG2):
+            np.testing.assert_allclose(f[k], a[k], rtol=1e-10, atol=1e-18)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), g1, rtol=1e-11, atol=1e-15)
+        xp = fo.shrink(x0 - tau * (A.T @ (-b / (1 + np.exp(b * (A @ x0))))), tau * mu)
+        z = A @ xp
+        np.testing.assert_allclose(f[hip.S_FSQ], np.sum(np.log(1 + np.exp(z)) - (b == 1) * z), rtol=1e-11)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), A.T @ (-b / (1 + np.exp(b * z))), rtol=1e-9, atol=1e-13)
+    finally:
+        op.close()
+
+
 def test_unsupported_shape_reports_and_auto_falls_back():
     A = np.random.RandomState(0).randn(20, 300)
     op = fa.DenseMatrixMap(A)
