@@ -755,28 +755,43 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 }
 
 // ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
-static int fused_ppt(fh_ctx* c) {          // pieces per lane, or 0 when the shape is not supported
-  if (c->op != OP_DENSE || c->ncu < FT_TEAM || c->ncu % FT_TEAM) return 0;
-  if (c->prox_kind == FH_PROX_TVBALL) return 0;
-  for (int ppt = 1; ppt <= 16; ppt *= 2)
-    if (c->ld / 2 == (uint64_t)FT_TEAM * FH_WG * ppt) return ppt;
-  return 0;
+// Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row (ld2 = TEAM*256*PPT).
+//   n = 4096*{1,2,4,8}: 8 members, exchange one trip ahead (fh_fused.h)
+//   n = 65536          : 16 members x 8 pieces, exchange one trip ahead (default), or -- FH_TUNE_FUSED_VARIANT bit 8 --
+//                        8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
+//   n = 131072         : 16 members x 16 pieces, exchange in line
+struct FusedShape { int ppt, team, pipe; };
+static FusedShape fused_shape(fh_ctx* c) {
+  FusedShape none = {0, 0, 0};
+  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ncu < FT_TEAM_MAX || c->ncu % FT_TEAM_MAX) return none;
+  if (c->n % (2 * FH_WG) || c->ld < c->n || c->ld % 2) return none;
+  const uint64_t pieces = c->n / 2;                  // 16-byte pieces per row (the row stride c->ld may be padded)
+  switch (pieces / FH_WG) {
+    case 8:   return {1, 8, 1};
+    case 16:  return {2, 8, 1};
+    case 32:  return {4, 8, 1};
+    case 64:  return {8, 8, 1};
+    case 128: return (c->fused_variant & 8) ? FusedShape{16, 8, 0} : FusedShape{8, 16, 1};
+    case 256: return {16, 16, 0};
+    default:  return none;
+  }
 }
+static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 
-template <int PPT, int KIND>
-static void launch_fused_pk(fh_ctx* c, const FusedP& p, unsigned grid) {
+template <int PPT, int KIND, int PIPE, int TEAM>
+static void launch_fused_k(fh_ctx* c, const FusedP& p, unsigned grid) {
   // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
-  k_fused_dense<PPT, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  k_fused_dense<PPT, 1, KIND, PIPE, TEAM><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
-template <int PPT>
+template <int PPT, int PIPE, int TEAM>
 static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) {
   switch (kind) {
-    case FH_PROX_SHRINK: launch_fused_pk<PPT, PX_SHRINK>(c, p, grid); break;
-    case FH_PROX_NONNEG: launch_fused_pk<PPT, PX_NONNEG>(c, p, grid); break;
-    case FH_PROX_LINF:   launch_fused_pk<PPT, PX_LINF>(c, p, grid); break;
-    case FH_PROX_L1BALL: launch_fused_pk<PPT, PX_L1BALL>(c, p, grid); break;
-    case FH_PROX_BOX:    launch_fused_pk<PPT, PX_BOX>(c, p, grid); break;
-    default:             launch_fused_pk<PPT, PX_IDENTITY>(c, p, grid); break;
+    case FH_PROX_SHRINK: launch_fused_k<PPT, PX_SHRINK, PIPE, TEAM>(c, p, grid); break;
+    case FH_PROX_NONNEG: launch_fused_k<PPT, PX_NONNEG, PIPE, TEAM>(c, p, grid); break;
+    case FH_PROX_LINF:   launch_fused_k<PPT, PX_LINF, PIPE, TEAM>(c, p, grid); break;
+    case FH_PROX_L1BALL: launch_fused_k<PPT, PX_L1BALL, PIPE, TEAM>(c, p, grid); break;
+    case FH_PROX_BOX:    launch_fused_k<PPT, PX_BOX, PIPE, TEAM>(c, p, grid); break;
+    default:             launch_fused_k<PPT, PX_IDENTITY, PIPE, TEAM>(c, p, grid); break;
   }
 }
 
@@ -788,19 +803,19 @@ struct FusedIO {
 };
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
-  const int ppt = fused_ppt(c);
-  if (!ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs dense A with n = 4096*{1,2,4,8,16})");
+  const FusedShape sh = fused_shape(c);
+  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs dense A with n = 4096*{1,2,4,8,16,32})");
   FusedP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
-  p.nteams = (uint32_t)(c->ncu / FT_TEAM);
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->n / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.nteams = (uint32_t)(c->ncu / sh.team);
   p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
   p.x0 = io.x0; p.g0 = io.g0; p.xhat = io.xhat; p.xp = io.xp;
   p.b = c->b; p.z = io.z; p.tau = tau; p.loss = c->loss_kind; p.mode = io.mode;
   p.px = make_prox(c, tau);
   p.px.kind = io.kind;
-  const unsigned grid = p.nteams * FT_TEAM;
-  const size_t slots_elems = (size_t)c->mp * FT_TEAM;
-  const size_t gpart_elems = (size_t)p.nteams * c->ld;
+  const unsigned grid = p.nteams * sh.team;
+  const size_t slots_elems = (size_t)c->mp * sh.team;
+  const size_t gpart_elems = (size_t)p.nteams * c->n;
   FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
   p.g1 = io.g1;
@@ -809,21 +824,28 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   t_begin(c, FH_K_FUSED);
   HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-  switch (ppt) {
-    case 1: launch_fused_p<1>(c, p, grid, io.kind); break;
-    case 2: launch_fused_p<2>(c, p, grid, io.kind); break;
-    case 4: launch_fused_p<4>(c, p, grid, io.kind); break;
-    case 8: launch_fused_p<8>(c, p, grid, io.kind); break;
-    default: launch_fused_p<16>(c, p, grid, io.kind); break;
+  if (sh.team == 8 && sh.pipe) {
+    switch (sh.ppt) {
+      case 1: launch_fused_p<1, 1, 8>(c, p, grid, io.kind); break;
+      case 2: launch_fused_p<2, 1, 8>(c, p, grid, io.kind); break;
+      case 4: launch_fused_p<4, 1, 8>(c, p, grid, io.kind); break;
+      default: launch_fused_p<8, 1, 8>(c, p, grid, io.kind); break;
+    }
+  } else if (sh.team == 8) {
+    launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
+  } else if (sh.pipe) {
+    launch_fused_p<8, 1, 16>(c, p, grid, io.kind);
+  } else {
+    launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
   }
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, n >= 32768):
+// z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, n >= 16384):
 // identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
-static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) >= 8; }
+static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && c->n >= 16384; }
 // returns 0 and sets *ok = false when the launch reported a spin timeout (caller falls back to two launches)
 static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bool* ok) {
   const FusedIO fio = {x, x, c->xhat, c->P[c->pc ^ 1], z, g, FH_PROX_IDENTITY, 2};
@@ -954,11 +976,11 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
   // 0 = unsupported; 1 = dense one-pass kernel, recommended (speculative: a rejected step wastes the A^T half);
   // 2 = stencil one-pass kernel (costs no more than K-fwd alone: it simply replaces both launches);
-  // 3 = dense one-pass kernel available but NOT recommended: the per-row team hand-off (~0.5-3 us) only pays once a
-  //     member's piece of a row streams for longer than that, i.e. n >= 32768 (profiles/r01c_fused_vs_two.txt:
-  //     32768^2 492 vs 403 it/s, 16384^2 1198 vs 1446 it/s)
+  // 3 = dense one-pass kernel available but NOT recommended: a trip of the row loop cannot go below ~0.66 us (barriers,
+  //     cross-lane sums, one scalar poll), which only pays once a team member's piece of a row is >= 16 KiB, i.e.
+  //     n >= 16384 (profiles/r01d_fused_tuning.txt: 16384^2 0.39 vs 0.66 ms, 8192^2 0.198 vs 0.180 ms)
   const int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
-  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt >= 8 ? 1 : (ppt ? 3 : 0));
+  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (c->n >= 16384 ? 1 : 3) : 0);
   return 0;
 }
 

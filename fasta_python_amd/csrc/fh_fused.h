@@ -2,18 +2,29 @@
 // single read of A (the two-launch path reads A twice: 2*m*n*8 bytes per iteration; this reads m*n*8).
 //
 // Why it is possible: g1 = sum_i a_i * r_i with r_i = grad f(a_i . xprox) -- row i is needed twice, first
-// whole (the dot product), then again for the rank-1 update.  A 512 KiB row does not fit one CU, so a TEAM of
-// 8 co-resident workgroups splits the columns: each member keeps its 1/8 of the row (PPT 16-byte pieces per
-// lane) IN REGISTERS, publishes its partial dot product as one write-through (`sc1`) 8-byte store into the
-// row's 64-byte slot line, polls the other seven (bounded spin), sums the eight partials in member order,
-// and applies r_i * (its row pieces) to its register-resident slice of g1.  Three row buffers rotate so that
-// two rows of loads are in flight while a row's partials are being exchanged (hand-off latency ~1-3 us per
-// the CDNA4 guide's price list vs ~2.4 us of streaming per row per CU).  The prox'd x slice also lives in
-// registers, computed once per launch.
+// whole (the dot product), then again for the rank-1 update.  A row (up to 1 MiB) does not fit one CU, so a TEAM
+// of 8 or 16 co-resident workgroups splits the columns: each member keeps its piece of the row (PPT 16-byte
+// pieces per lane) IN REGISTERS, publishes its partial dot product as one write-through (`sc1`) 8-byte store into
+// the row's slot line(s), reads the whole line back with scalar loads until no slot holds the sentinel (bounded),
+// sums the partials in member order, and applies r_i * (its row pieces) to its register-resident slice of g1.
+// The prox'd x slice also lives in registers, computed once per launch.
 //
-//   grid  = (#CUs / 8) teams x 8 members, 256 threads, 1 workgroup per CU (~330 VGPRs => 1 wave per SIMD), so
-//           the whole grid is co-resident by construction; every spin is bounded by wall-clock and raises
-//           p.err instead of hanging if that assumption is ever violated.
+// Two schedules of the row loop (template parameter PIPE; the host picks per shape, fasta_hip.hip:fused_shape):
+//   PIPE = 1  "exchange one trip ahead": in trip t the team posts row t+1 and waits for row t, which was posted a
+//             whole trip earlier, so the ~0.5 us hand-off is off the critical path; NB = 5-6 row buffers rotate
+//             (row t held until its update, row t+1 until the next trip, the rest prefetching).  PPT <= 8.
+//   PIPE = 0  exchange in line (post row t, wait for row t, update): three buffers of PPT = 16 pieces are all the
+//             512 registers hold; two rows of loads stay in flight during the exchange.
+// What made the loop fast (each step measured, profiles/r01b_tune_fused.txt and r01d_fused_tuning.txt):
+//   * raw `s_barrier` + lgkmcnt-only waits, branch-free unconditional (clamped) prefetches and b[r] via s_load, so that
+//     hipcc's waitcnt pass keeps counted `vmcnt(N)` waits instead of draining every prefetched row each trip;
+//   * the slot poll uses SCALAR loads: a vector poll's `vmcnt(0)` also waits for the wave's own prefetch (one HBM
+//     latency per trip) and for its write-through store's acknowledgement;
+//   * the post is issued by wave 1, the poll by wave 0; cross-lane sums by DPP/readlane instead of ds_bpermute.
+//
+//   grid  = (#CUs / TEAM) teams x TEAM members, 256 threads, 1 workgroup per CU (all 512 registers => 1 wave per
+//           SIMD), so the whole grid is co-resident by construction; every spin is bounded and raises p.err
+//           instead of hanging if that assumption is ever violated.
 //   team t owns rows [t*rows_per_team, ...); member j owns 16-byte pieces [j*256*PPT, (j+1)*256*PPT).
 //   After the rows: slice partials -> workspace, bounded grid barrier, then all workgroups sum the team
 //   partials for their share of the columns in team order and run the n-side epilogue (same arithmetic as
@@ -22,24 +33,50 @@
 // Used speculatively by the host driver (solver.py): the launch assumes the step will be accepted; if the
 // backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj as usual (identical
 // results either way).  Requires no acceleration (the FISTA coefficient depends on this launch's own
-// restart dot) and ld2 == 8*256*PPT (n = 4096*PPT, PPT in {1,2,4,8,16}); anything else uses the two-launch path.
+// restart dot) and n = TEAM*256*2*PPT exactly, i.e. n = 4096*{1,2,4,8,16,32}; anything else uses the two-launch path.
 #pragma once
 #include "fh_dense.h"
 
-#define FT_TEAM 8
+#define FT_TEAM_MAX 16                              // members per team: 8 or 16 (template parameter TEAM)
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock (grid barrier)
-#define FT_SPIN_POLLS 400000u                       // slot-poll budget: ~1.2 us per poll (sc1 load + s_sleep) => ~0.5 s
+#define FT_SPIN_POLLS 1000000u                      // slot-poll budget: ~0.3-0.5 us per poll (s_load glc + s_sleep) => ~0.4 s
 
 // Workgroup barrier for LDS hand-offs inside the row loop.  `__syncthreads()` makes hipcc drain `vmcnt(0)` first,
 // which would land every prefetched row before each of the two per-row barriers (pipeline depth 0); this waits
 // for the LDS traffic only and leaves the row loads in flight.
 __device__ __forceinline__ void ft_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Cross-lane sums without LDS round trips (the row loop's serial chain is dot -> wave sum -> barrier -> exchange ->
+// barrier -> update; `__shfl_down` lowers to ds_bpermute, ~100 cycles per step and six dependent steps per row).
+template <int CTRL>
+__device__ __forceinline__ double ft_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ft_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double ft_wave_sum(double v) {       // every lane gets the same sum (fixed order)
+  v += ft_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += ft_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += ft_dpp<0x141>(v);      // row_half_mirror
+  v += ft_dpp<0x140>(v);      // row_mirror: every lane of a 16-lane row holds the row's sum
+  return ((ft_readlane(v, 0) + ft_readlane(v, 16)) + ft_readlane(v, 32)) + ft_readlane(v, 48);
+}
+
+// -DFT_PROFILE: wave 0 of block 0 accumulates s_memtime ticks per phase of the row loop and prints them (debug builds only)
+#ifdef FT_PROFILE
+#define FT_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); prof[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define FT_T(i) do { } while (0)
+#endif
+
 struct FusedP {
   const double* A;
   uint64_t ld;
-  uint32_t ld2, n, m, mp;
+  uint32_t ld2, n, m, mp;   // ld2: 16-byte pieces covered by a team (TEAM*256*PPT); ld: row stride of A in doubles (>= 2*ld2)
   uint32_t nteams, rows_per_team;
   const double* x0; const double* g0;
   double* xhat; double* xp;
@@ -54,7 +91,7 @@ struct FusedP {
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
   unsigned* err;         // set to 1 on a spin timeout
-  int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep in the poll, 64 = fault injection (tests)
+  int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
   double* out;
 };
 
@@ -62,15 +99,15 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-template <int PPT, int NT, int KIND>
+template <int PPT, int NT, int KIND, int PIPE, int TEAM>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / FT_TEAM;
-  const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % FT_TEAM;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: scalar
+  const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / TEAM;
+  const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % TEAM;
   const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
   const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
 
@@ -109,120 +146,236 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   }
 
   // ---------------- rows of this team: one pass, three rotating register buffers ----------------------------
-  const uint32_t r_begin = min(team * p.rows_per_team, p.mp);
-  const uint32_t r_end = min(r_begin + p.rows_per_team, p.mp);
+  // Row numbers below are TEAM-LOCAL (0 .. r_end-1); grow() maps them to rows of A.  Default: blocked (team t owns a
+  // contiguous range of rows_per_team rows); variant bit 32: row-cyclic over the teams (t, t+nteams, ...), i.e. the whole
+  // grid streams one contiguous window of nteams rows -- measured equal or a little slower (profiles/r01d_fused_tuning.txt).
+  const bool blocked = (p.variant & 32) == 0;
+  const uint32_t row_base = blocked ? min(team * p.rows_per_team, p.mp) : team;
+  const uint32_t row_step = blocked ? 1u : p.nteams;
+  const uint32_t r_begin = 0u;
+  const uint32_t r_end = blocked ? min(row_base + p.rows_per_team, p.mp) - row_base
+                                 : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
   const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
+  auto grow = [&](uint32_t r) { return row_base + r * row_step; };
   const d2* Abase = reinterpret_cast<const d2*>(p.A) + c0;
   d2 ga[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
   double fs = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
+#ifdef FT_PROFILE
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
 
   // Row loads are UNCONDITIONAL (callers clamp the row index to the team's last row; the two surplus reads per team are
   // noise): hipcc's waitcnt pass merges the pending-load state of both sides of any branch by taking the SMALLER
   // outstanding count, so a skipped prefetch on one path turns every later `s_waitcnt vmcnt(N)` into "wait for the
   // newest loads too" -- i.e. no prefetch distance at all.
   auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
-    const d2* src = Abase + (uint64_t)r * p.ld2;
+    const d2* src = Abase + (uint64_t)grow(r) * (p.ld / 2);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + k * FH_WG);
   };
-  // `vmcnt` retires in order: the polling wave (0) must not have a freshly issued row ahead of its poll loads, so it
-  // issues the reload of the freed buffer AFTER the poll; waves 1-3 issue it up front (two rows in flight).
-  auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
-    load_row(nbuf, min(nr, r_last));
-    // b[r] through the scalar cache (constant address space => s_load, counted by lgkmcnt): as a vector load inside the
-    // lane-0 branch below it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
-    const double bi = ((const __attribute__((address_space(4))) double*)(uintptr_t)p.b)[r];
+  // wave 0 (uniform): wait for the eight partials of row r (bounded), return their sum in member order.
+  // The slot line is polled with SCALAR loads (`s_load_dwordx16 glc`: past the scalar cache, all eight slots at
+  // once): they count on lgkmcnt, so the poll neither waits for this wave's prefetched rows nor for its stores --
+  // a vector poll's `s_waitcnt vmcnt(0)` did both (vmcnt retires in order), which put one HBM latency into every
+  // trip.  Measured hand-off (scripts/bench_mem/handoff.hip): sc1 store -> s_load glc ~0.5 us within and across
+  // XCDs, sc1 store -> sc1 vector load 0.6-0.9 us.  The loop itself is plain C around the asm load: it contains no
+  // compiler-visible vector memory operation, so hipcc's vmcnt bookkeeping for the row buffers stays exact.
+  auto poll_row = [&](uint32_t r, bool live) -> double {
+    typedef unsigned ft_line __attribute__((ext_vector_type(16)));
+    constexpr int NL = TEAM / 8;                   // 64-byte slot lines per row
+    ft_line line[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) line[l][j] = 0u;
+    if (live && !dead) {
+      const double* lp = p.slots + (uint64_t)grow(r) * TEAM;
+      unsigned cnt = 0u;
+      for (;;) {
+        if (NL == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
+        else asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                          : "=&s"(line[0]), "=&s"(line[NL - 1]) : "s"(lp) : "memory");
+        bool pending = false;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pending |= line[l][2 * j + 1] == FT_SENTINEL_HI;
+        if (!pending) break;
+        if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch (no p.err load in the
+          dead = true;                  // loop: a C-level load there would drain every prefetched row each trip)
+          if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (line[l][2 * j + 1] == FT_SENTINEL_HI) { line[l][2 * j] = 0u; line[l][2 * j + 1] = 0u; }
+          break;
+        }
+        if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    double zs = __hiloint2double((int)line[0][1], (int)line[0][0]);
+#pragma unroll
+    for (int j = 1; j < TEAM; ++j) zs += __hiloint2double((int)line[j / 8][2 * (j % 8) + 1], (int)line[j / 8][2 * (j % 8)]);   // member order: deterministic
+    return zs;
+  };
+  // lane 0 of ONE wave, after the barrier that follows the s_part writes: publish this member's partial of row r
+  auto post_row = [&](uint32_t r, bool live) {
+    // variant bit 64 = FAULT INJECTION for the test-suite: member 7 of team 0 never publishes its first row, so its
+    // team-mates must hit the poll budget, raise p.err and let the whole grid drain (no hang)
+    const bool sabotage = (p.variant & 64) && team == 0 && mem == TEAM - 1 && r == r_begin;
+    if (lane == 0 && live && !sabotage)
+      store_partial(p.slots + (uint64_t)grow(r) * TEAM + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+  };
+  auto dot_row = [&](const d2 (&buf)[PPT]) -> double {
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       part = fma(buf[k].x, xq[k].x, part);
       part = fma(buf[k].y, xq[k].y, part);
     }
-    part = wave_sum(part);
-    if (lane == 0) s_part[wave] = part;
-    ft_lds_barrier();
-    if (wave == 0) {
-      double* line = p.slots + (uint64_t)r * FT_TEAM;
-      // variant bit 64 = FAULT INJECTION for the test-suite: member 7 of team 0 never publishes its first row, so its
-      // team-mates must hit the wall-clock bound, raise p.err and let the whole grid drain (no hang)
-      const bool sabotage = (p.variant & 64) && team == 0 && mem == FT_TEAM - 1 && r == r_begin;
-      if (lane == 0 && !sabotage) store_partial(line + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
-      double val = 0.0;
-      if (lane < FT_TEAM && !dead) {
-        // The poll loop is written in asm on purpose: a C loop with loads inside this wave-0-only branch makes hipcc's
-        // waitcnt pass lose count at the join and emit `s_waitcnt vmcnt(0)` before every later use of the row buffers in
-        // ALL waves (measured: pipeline depth 0).  Hidden in asm, the compiler keeps exact counts for the row loads.
-        // Bounded by an iteration budget (~0.5 s with the sleep) instead of the clock to stay within 32-bit scalar ops.
-        const double* slot = line + lane;
-        const unsigned long long sent = ((unsigned long long)FT_SENTINEL_HI << 32) | FT_SENTINEL_HI;
-        unsigned long long tmp;
-        unsigned cnt = 0u, timed_out;
-        asm volatile(
-            "s_mov_b32 %[to], 0\n"
-            "1:\n\t"
-            "global_load_dwordx2 %[val], %[addr], off sc1\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
-            "v_cmp_ne_u64 vcc, %[sent], %[val]\n\t"
-            "s_andn2_b64 %[tmp], exec, vcc\n\t"
-            "s_cbranch_scc0 2f\n\t"
-            "s_sleep 1\n\t"
-            "s_add_u32 %[cnt], %[cnt], 1\n\t"
-            "s_cmp_lt_u32 %[cnt], %[max]\n\t"
-            "s_cbranch_scc1 1b\n\t"
-            "s_mov_b32 %[to], 1\n"
-            "2:\n"
-            : [val] "=&v"(val), [tmp] "=&s"(tmp), [cnt] "+s"(cnt), [to] "=&s"(timed_out)
-            : [addr] "v"(slot), [sent] "s"(sent), [max] "s"(FT_SPIN_POLLS)
-            : "vcc", "scc", "memory");
-        if (timed_out) {       // give up on the exchange for the rest of the launch (no p.err load in the loop:
-          dead = true;         // a C-level load there would drain every prefetched row each trip)
-          __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ft_is_sentinel(val)) val = 0.0;
-        }
-      }
-      double zs = __shfl(val, 0, 64);
-#pragma unroll
-      for (int j = 1; j < FT_TEAM; ++j) zs += __shfl(val, j, 64);   // member order: deterministic
-      if (lane == 0) {
-        s_bc[0] = loss_grad(zs, bi, p.loss);
-        if (mem == 0) store_partial(p.z + r, zs);                    // read back below by other lanes of this workgroup
-      }
-    }
-    ft_lds_barrier();
-    const double rv = s_bc[0];
+    return ft_wave_sum(part);
+  };
+  auto update_row = [&](const d2 (&buf)[PPT], double rv) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       ga[k].x = fma(buf[k].x, rv, ga[k].x);
       ga[k].y = fma(buf[k].y, rv, ga[k].y);
     }
   };
+  // b[r] through the scalar cache (constant address space => s_load, counted by lgkmcnt): as a vector load inside a
+  // lane-0 branch it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
+  const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
 
-  if (r_begin < r_end) {
-    d2 b0[PPT], b1[PPT], b2[PPT];
-    load_row(b0, r_begin);
-    load_row(b1, min(r_begin + 1u, r_last));
-    uint32_t r = r_begin;
-    for (; r + 3u <= r_end; r += 3u) {              // branch-free body: exact vmcnt distances (two rows stay in flight)
-      process_row(b0, r, b2, r + 2u);
-      process_row(b1, r + 1u, b0, r + 3u);
-      process_row(b2, r + 2u, b1, r + 4u);
+  if constexpr (!PIPE) {
+    // ---- exchange in line: prefetch r+2 | dot r | exchange r | update r  (two rows in flight during the exchange)
+    auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
+      load_row(nbuf, min(nr, r_last));
+      const double bi = bq[grow(r)];
+      FT_T(0);
+      const double part = dot_row(buf);
+      FT_T(1);
+      if (lane == 0) s_part[wave] = part;
+      ft_lds_barrier();
+      FT_T(2);
+      if (wave == 0) {
+        post_row(r, true);
+        FT_T(3);
+        const double zs = poll_row(r, true);
+        FT_T(4);
+        if (lane == 0) {
+          s_bc[0] = loss_grad(zs, bi, p.loss);
+          if (mem == 0) store_partial(p.z + grow(r), zs);              // read back below by other lanes of this workgroup
+        }
+      }
+      FT_T(5);
+      ft_lds_barrier();
+      FT_T(6);
+      update_row(buf, s_bc[0]);
+      FT_T(7);
+    };
+    if (r_begin < r_end) {
+      d2 b0[PPT], b1[PPT], b2[PPT];
+      load_row(b0, r_begin);
+      load_row(b1, min(r_begin + 1u, r_last));
+      uint32_t r = r_begin;
+      for (; r + 3u <= r_end; r += 3u) {              // branch-free body: exact vmcnt distances (two rows stay in flight)
+        process_row(b0, r, b2, r + 2u);
+        process_row(b1, r + 1u, b0, r + 3u);
+        process_row(b2, r + 2u, b1, r + 4u);
+      }
+      if (r < r_end) {
+        process_row(b0, r, b2, r + 2u);
+        if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
+      }
     }
-    if (r < r_end) {
-      process_row(b0, r, b2, r + 2u);
-      if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
+  } else if (r_begin < r_end) {
+    // ---- exchange one trip ahead: in trip t the team posts its partials of row t+1 and only then waits for row t's
+    // (posted a whole trip earlier, so the poll normally hits at once): the hand-off latency leaves the critical path.
+    // Wave 0 (the polling wave) and waves 1-3 run SEPARATE loops with the same barrier count: wave 0 issues its
+    // prefetch after its poll (vmcnt retires in order: a fresh row ahead of the poll load would stall it).
+    // NB register buffers rotate: row t is held until its update, row t+1 until the next trip, NB-2 rows prefetch.
+    // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
+    constexpr int NB = PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6);
+    d2 B[NB][PPT];
+    const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+    if (wave == 0) {
+      const double d0 = dot_row(B[0]);
+      if (lane == 0) s_part[0] = d0;
+      ft_lds_barrier();
+      ft_lds_barrier();
+      for (uint32_t t = 0; t < trips; t += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint32_t r = r_begin + t + j;
+          const bool live = r < r_end;
+          const double bi = bq[grow(min(r, r_last))];
+          load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
+          FT_T(0);
+          const double d = dot_row(B[(j + 1) % NB]);
+          if (lane == 0) s_part[0] = d;
+          FT_T(1);
+          ft_lds_barrier();                                        // wave 1 posts row r+1 from s_part[0..3]
+          FT_T(2);
+          FT_T(3);
+          const double zs = poll_row(r, live);
+          FT_T(4);
+          if (lane == 0) {
+            s_bc[0] = live ? loss_grad(zs, bi, p.loss) : 0.0;
+            if (mem == 0 && live) store_partial(p.z + grow(r), zs);
+          }
+          FT_T(5);
+          ft_lds_barrier();
+          FT_T(6);
+          update_row(B[j], s_bc[0]);
+          FT_T(7);
+        }
+      }
+    } else {
+      const double d0 = dot_row(B[0]);
+      if (lane == 0) s_part[wave] = d0;
+      ft_lds_barrier();
+      if (wave == 1) post_row(r_begin, true);
+      ft_lds_barrier();
+      for (uint32_t t = 0; t < trips; t += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint32_t r = r_begin + t + j;
+          load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
+          const double d = dot_row(B[(j + 1) % NB]);
+          if (lane == 0) s_part[wave] = d;
+          ft_lds_barrier();
+          // the post is wave 1's, the poll wave 0's: `vmcnt` also counts stores, and a write-through store is only
+          // acknowledged ~0.5 us later -- issued by the polling wave it would hold up every poll's `vmcnt(0)`
+          if (wave == 1) post_row(r + 1u, r + 1u < r_end);
+          ft_lds_barrier();
+          update_row(B[j], s_bc[0]);
+        }
+      }
     }
   }
 
+#ifdef FT_PROFILE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("fused profile (block 0 wave 0, %u rows; s_memtime ticks per row): top %.1f dot %.1f bar1 %.1f post %.1f poll %.1f bcast %.1f bar2 %.1f update %.1f\n",
+           r_end - r_begin, (double)prof[0] / (r_end - r_begin), (double)prof[1] / (r_end - r_begin), (double)prof[2] / (r_end - r_begin),
+           (double)prof[3] / (r_end - r_begin), (double)prof[4] / (r_end - r_begin), (double)prof[5] / (r_end - r_begin),
+           (double)prof[6] / (r_end - r_begin), (double)prof[7] / (r_end - r_begin));
+#endif
   // ---------------- loss terms of this team's rows (member 0), off the exchange's critical path: keeping log/exp of the
   // logistic objective out of the row loop also keeps their constants out of its (full) register budget
   if (mem == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
-    for (uint32_t r = r_begin + tid; r < min(r_end, p.m); r += FH_WG) fs += loss_term(load_partial(p.z + r), bq[r], p.loss);
+    for (uint32_t i = tid; i < r_end; i += FH_WG) {
+      const uint32_t r = grow(i);
+      if (r < p.m) fs += loss_term(load_partial(p.z + r), bq[r], p.loss);
+    }
   }
 
   // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------

@@ -138,11 +138,11 @@ int fh_fwd(fh_ctx* ctx, double tau, double* scalars);
  * g1 = A^H (z1' - b) (:248); reductions FH_S_DXDG..FH_S_GMAX_ADJ (:254-260, 274, 285).          */
 int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
 /* ONE-PASS iteration (dense operator, no acceleration): K-fwd and K-adj of the same tau from a SINGLE read of A
- * (teams of 8 co-resident workgroups exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
+ * (teams of 8 or 16 co-resident workgroups exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
  * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it
  * speculatively: if the backtracking test on FH_S_FSQ fails it re-runs fh_fwd (smaller tau) + fh_adj.
- * fh_fused_supported: 0 = no; 1 = dense, recommended (n = 4096*{8,16}); 3 = dense, available but slower than the two
- * launches (n = 4096*{1,2,4}); 2 = stencil operator (one sweep replaces both launches).                              */
+ * fh_fused_supported: 0 = no; 1 = dense, recommended (n = 4096*{4,8,16,32}); 3 = dense, available but slower than the
+ * two launches (n = 4096*{1,2}); 2 = stencil operator (one sweep replaces both launches).                            */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
