@@ -757,7 +757,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 // ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
 // Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row (ld2 = TEAM*256*PPT).
 //   n = 4096*{1,2,4,8}: 8 members, exchange one trip ahead (fh_fused.h)
-//   n = 65536          : 16 members x 8 pieces, exchange one trip ahead (default), or -- FH_TUNE_FUSED_VARIANT bit 8 --
+//   n = 65536          : 16 members x 8 pieces, exchange two trips ahead (default), or -- FH_TUNE_FUSED_VARIANT bit 8 --
 //                        8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
 //   n = 131072         : 16 members x 16 pieces, exchange in line
 struct FusedShape { int ppt, team, pipe; };
@@ -834,7 +834,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   } else if (sh.team == 8) {
     launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
   } else if (sh.pipe) {
-    launch_fused_p<8, 1, 16>(c, p, grid, io.kind);
+    launch_fused_p<8, 2, 16>(c, p, grid, io.kind);       // 16 members: posts run two rows ahead of the polls
   } else {
     launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
   }

@@ -10,9 +10,10 @@
 // The prox'd x slice also lives in registers, computed once per launch.
 //
 // Two schedules of the row loop (template parameter PIPE; the host picks per shape, fasta_hip.hip:fused_shape):
-//   PIPE = 1  "exchange one trip ahead": in trip t the team posts row t+1 and waits for row t, which was posted a
-//             whole trip earlier, so the ~0.5 us hand-off is off the critical path; NB = 5-6 row buffers rotate
-//             (row t held until its update, row t+1 until the next trip, the rest prefetching).  PPT <= 8.
+//   PIPE = D >= 1  "exchange D trips ahead": in trip t the team posts row t+D and waits for row t, which was posted D
+//             whole trips earlier, so the ~0.5 us hand-off is off the critical path; NB = 5-6 row buffers rotate
+//             (rows t..t+D held until their updates, the rest prefetching).  PPT <= 8.  D = 1 for teams of 8,
+//             D = 2 for teams of 16 (more members, more skew: 65536^2 5.25 -> 4.99 ms).
 //   PIPE = 0  exchange in line (post row t, wait for row t, update): three buffers of PPT = 16 pieces are all the
 //             512 registers hold; two rows of loads stay in flight during the exchange.
 // What made the loop fast (each step measured, profiles/r01b_tune_fused.txt and r01d_fused_tuning.txt):
@@ -299,16 +300,21 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // prefetch after its poll (vmcnt retires in order: a fresh row ahead of the poll load would stall it).
     // NB register buffers rotate: row t is held until its update, row t+1 until the next trip, NB-2 rows prefetch.
     // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
-    constexpr int NB = PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6);
+    constexpr int D = PIPE;                                        // rows between a post and its poll
+    constexpr int NB = PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6);         // D+1 rows are held, NB-1-D rows prefetch
+    static_assert(NB >= D + 2, "need at least one prefetching buffer");
     d2 B[NB][PPT];
     const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
     if (wave == 0) {
-      const double d0 = dot_row(B[0]);
-      if (lane == 0) s_part[0] = d0;
-      ft_lds_barrier();
-      ft_lds_barrier();
+#pragma unroll
+      for (int q = 0; q < D; ++q) {                                // rows 0..D-1 are posted before the first trip
+        const double d0 = dot_row(B[q]);
+        if (lane == 0) s_part[0] = d0;
+        ft_lds_barrier();
+        ft_lds_barrier();
+      }
       for (uint32_t t = 0; t < trips; t += NB) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -317,10 +323,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           const double bi = bq[grow(min(r, r_last))];
           load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
           FT_T(0);
-          const double d = dot_row(B[(j + 1) % NB]);
+          const double d = dot_row(B[(j + D) % NB]);
           if (lane == 0) s_part[0] = d;
           FT_T(1);
-          ft_lds_barrier();                                        // wave 1 posts row r+1 from s_part[0..3]
+          ft_lds_barrier();                                        // wave 1 posts row r+D from s_part[0..3]
           FT_T(2);
           FT_T(3);
           const double zs = poll_row(r, live);
@@ -337,22 +343,25 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
         }
       }
     } else {
-      const double d0 = dot_row(B[0]);
-      if (lane == 0) s_part[wave] = d0;
-      ft_lds_barrier();
-      if (wave == 1) post_row(r_begin, true);
-      ft_lds_barrier();
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const double d0 = dot_row(B[q]);
+        if (lane == 0) s_part[wave] = d0;
+        ft_lds_barrier();
+        if (wave == 1) post_row(r_begin + q, r_begin + q < r_end);
+        ft_lds_barrier();
+      }
       for (uint32_t t = 0; t < trips; t += NB) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const uint32_t r = r_begin + t + j;
           load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
-          const double d = dot_row(B[(j + 1) % NB]);
+          const double d = dot_row(B[(j + D) % NB]);
           if (lane == 0) s_part[wave] = d;
           ft_lds_barrier();
           // the post is wave 1's, the poll wave 0's: `vmcnt` also counts stores, and a write-through store is only
           // acknowledged ~0.5 us later -- issued by the polling wave it would hold up every poll's `vmcnt(0)`
-          if (wave == 1) post_row(r + 1u, r + 1u < r_end);
+          if (wave == 1) post_row(r + D, r + D < r_end);
           ft_lds_barrier();
           update_row(B[j], s_bc[0]);
         }

@@ -25,7 +25,7 @@ def timed(fn, kid, reps=6):
 
 
 for rnd in range(2):
-    for variant in (2, 34, 10):
+    for variant in (2, 10):
         ctx.set_tuning(hip.TUNE_FUSED_VARIANT, variant)
         t = timed(lambda: ctx.step(0.2), hip.K_FUSED)
         print(f"round {rnd} variant {variant} (defer={variant & 1} xcd={(variant >> 1) & 1} prefetch_deferred={variant & 1}): "
