@@ -755,26 +755,27 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 }
 
 // ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
-// Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row (ld2 = TEAM*256*PPT).
-//   n = 4096*{1,2,4,8}: 8 members, exchange one trip ahead (fh_fused.h)
-//   n = 65536          : 16 members x 8 pieces, exchange two trips ahead (default), or -- FH_TUNE_FUSED_VARIANT bit 8 --
-//                        8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
-//   n = 131072         : 16 members x 16 pieces, exchange in line
+// Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row; lanes past the row's last
+// piece are masked (clamped loads, zero x), so any n up to 131072 fits the next shape up:
+//   n <= 32768 : 8 members x PPT = ceil(n/4096) pieces (rounded up to 1, 2, 4 below 16384), posts one row ahead
+//   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead; FH_TUNE_FUSED_VARIANT bit 8 and n = 65536:
+//                8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
+//   n <= 131072: 16 members x 16 pieces, exchange in line
 struct FusedShape { int ppt, team, pipe; };
 static FusedShape fused_shape(fh_ctx* c) {
   FusedShape none = {0, 0, 0};
   if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ncu < FT_TEAM_MAX || c->ncu % FT_TEAM_MAX) return none;
-  if (c->n % (2 * FH_WG) || c->ld < c->n || c->ld % 2) return none;
-  const uint64_t pieces = c->n / 2;                  // 16-byte pieces per row (the row stride c->ld may be padded)
-  switch (pieces / FH_WG) {
-    case 8:   return {1, 8, 1};
-    case 16:  return {2, 8, 1};
-    case 32:  return {4, 8, 1};
-    case 64:  return {8, 8, 1};
-    case 128: return (c->fused_variant & 8) ? FusedShape{16, 8, 0} : FusedShape{8, 16, 1};
-    case 256: return {16, 16, 0};
-    default:  return none;
+  if (c->ld % 2 || c->n == 0) return none;
+  const uint64_t pieces = round_up(c->n, 16) / 2;    // 16-byte pieces per row that hold data (the row stride c->ld may be padded)
+  if (pieces > c->ld / 2 || pieces > (uint64_t)16 * FH_WG * 16) return none;
+  if (pieces <= (uint64_t)8 * FH_WG * 8) {
+    int ppt = (int)((pieces + 8 * FH_WG - 1) / (8 * FH_WG));
+    if (ppt == 3) ppt = 4;
+    return {ppt, 8, 1};
   }
+  if (pieces == (uint64_t)8 * FH_WG * 16 && (c->fused_variant & 8)) return {16, 8, 0};
+  if (pieces <= (uint64_t)16 * FH_WG * 8) return {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2};
+  return {16, 16, 0};
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 
@@ -804,9 +805,9 @@ struct FusedIO {
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const FusedShape sh = fused_shape(c);
-  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs dense A with n = 4096*{1,2,4,8,16,32})");
+  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 131072 and a scalar-separable prox)");
   FusedP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->n / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.nteams = (uint32_t)(c->ncu / sh.team);
   p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
   p.x0 = io.x0; p.g0 = io.g0; p.xhat = io.xhat; p.xp = io.xp;
@@ -815,7 +816,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.px.kind = io.kind;
   const unsigned grid = p.nteams * sh.team;
   const size_t slots_elems = (size_t)c->mp * sh.team;
-  const size_t gpart_elems = (size_t)p.nteams * c->n;
+  const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
   FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
   p.g1 = io.g1;
@@ -829,12 +830,20 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
       case 1: launch_fused_p<1, 1, 8>(c, p, grid, io.kind); break;
       case 2: launch_fused_p<2, 1, 8>(c, p, grid, io.kind); break;
       case 4: launch_fused_p<4, 1, 8>(c, p, grid, io.kind); break;
+      case 5: launch_fused_p<5, 1, 8>(c, p, grid, io.kind); break;
+      case 6: launch_fused_p<6, 1, 8>(c, p, grid, io.kind); break;
+      case 7: launch_fused_p<7, 1, 8>(c, p, grid, io.kind); break;
       default: launch_fused_p<8, 1, 8>(c, p, grid, io.kind); break;
     }
   } else if (sh.team == 8) {
     launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
-  } else if (sh.pipe) {
-    launch_fused_p<8, 2, 16>(c, p, grid, io.kind);       // 16 members: posts run two rows ahead of the polls
+  } else if (sh.pipe) {                      // 16 members: posts run two rows ahead of the polls
+    switch (sh.ppt) {
+      case 5: launch_fused_p<5, 2, 16>(c, p, grid, io.kind); break;
+      case 6: launch_fused_p<6, 2, 16>(c, p, grid, io.kind); break;
+      case 7: launch_fused_p<7, 2, 16>(c, p, grid, io.kind); break;
+      default: launch_fused_p<8, 2, 16>(c, p, grid, io.kind); break;
+    }
   } else {
     launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
   }

@@ -34,7 +34,8 @@
 // Used speculatively by the host driver (solver.py): the launch assumes the step will be accepted; if the
 // backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj as usual (identical
 // results either way).  Requires no acceleration (the FISTA coefficient depends on this launch's own
-// restart dot) and n = TEAM*256*2*PPT exactly, i.e. n = 4096*{1,2,4,8,16,32}; anything else uses the two-launch path.
+// restart dot) and n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
+// address, carry x = 0 and are masked out of every store (fasta_hip.hip:fused_shape picks the next shape up).
 #pragma once
 #include "fh_dense.h"
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ double ft_wave_sum(double v) {       // every lane ge
 struct FusedP {
   const double* A;
   uint64_t ld;
-  uint32_t ld2, n, m, mp;   // ld2: 16-byte pieces covered by a team (TEAM*256*PPT); ld: row stride of A in doubles (>= 2*ld2)
+  uint32_t ld2, n, m, mp;   // ld2: 16-byte pieces of a row that hold data (round_up(n,16)/2 <= TEAM*256*PPT); ld: row stride of A in doubles
   uint32_t nteams, rows_per_team;
   const double* x0; const double* g0;
   double* xhat; double* xp;
@@ -118,8 +119,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const uint32_t c = c0 + k * FH_WG;
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-    const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
+    const uint32_t cl = min(c, p.ld2 - 1u);          // lanes past the row's last piece re-read it (results masked out)
+    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[cl];
+    const d2 g0v = reinterpret_cast<const d2*>(p.g0)[cl];
     d2 xh, xp;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       }
     }
     xq[k] = xp;
-    if (team == 0) {            // write-through: other workgroups read these back after the grid barrier
+    if (team == 0 && c < p.ld2) {   // write-through: other workgroups read these back after the grid barrier
       store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
       store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
     }
@@ -158,7 +160,6 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
                                  : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
   const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
   auto grow = [&](uint32_t r) { return row_base + r * row_step; };
-  const d2* Abase = reinterpret_cast<const d2*>(p.A) + c0;
   d2 ga[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
@@ -172,10 +173,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // noise): hipcc's waitcnt pass merges the pending-load state of both sides of any branch by taking the SMALLER
   // outstanding count, so a skipped prefetch on one path turns every later `s_waitcnt vmcnt(N)` into "wait for the
   // newest loads too" -- i.e. no prefetch distance at all.
-  auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
-    const d2* src = Abase + (uint64_t)grow(r) * (p.ld / 2);
+  uint32_t pc[PPT];                                  // this lane's piece indices, clamped to the row's last piece
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + k * FH_WG);
+  for (int k = 0; k < PPT; ++k) pc[k] = min(c0 + k * FH_WG, p.ld2 - 1u);
+  auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
+    const d2* src = reinterpret_cast<const d2*>(p.A) + (uint64_t)grow(r) * (p.ld / 2);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + pc[k]);
   };
   // wave 0 (uniform): wait for the eight partials of row r (bounded), return their sum in member order.
   // The slot line is polled with SCALAR loads (`s_load_dwordx16 glc`: past the scalar cache, all eight slots at
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------
 #pragma unroll
   for (int k = 0; k < PPT; ++k)
-    store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
+    if (c0 + k * FH_WG < p.ld2) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
   {
     double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], 0.0};
     block_reduce<8>(w, s_scr, 6);

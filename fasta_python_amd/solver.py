@@ -168,7 +168,7 @@ class FBSolver:
         # stencil: the one-pass kernel costs no more than K-fwd alone, so it also serves the backtracking retries
         self.fused_always = kind == 2
         if self.fused_opt is True and not self.use_fused:
-            raise ValueError("fused=True needs accelerate=False and a stencil operator or a dense one with n = 4096*{1,2,4,8,16,32}")
+            raise ValueError("fused=True needs accelerate=False and a stencil operator or a dense one with n <= 131072")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
         self.alpha1 = 1.0                                               # :157

@@ -141,8 +141,8 @@ int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
  * (teams of 8 or 16 co-resident workgroups exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
  * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it
  * speculatively: if the backtracking test on FH_S_FSQ fails it re-runs fh_fwd (smaller tau) + fh_adj.
- * fh_fused_supported: 0 = no; 1 = dense, recommended (n = 4096*{4,8,16,32}); 3 = dense, available but slower than the
- * two launches (n = 4096*{1,2}); 2 = stencil operator (one sweep replaces both launches).                            */
+ * fh_fused_supported: 0 = no (n > 131072, TV prox on a dense operator); 1 = dense, recommended (16384 <= n <= 131072);
+ * 3 = dense, available but slower than the two launches (n < 16384); 2 = stencil operator (one sweep replaces both).  */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also

@@ -25,7 +25,9 @@ def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
 # exchange in line (default there: 16 members x 8 pieces, exchange one trip ahead); n=131072 always runs 16 x 16 in line
 @pytest.mark.parametrize("variant", [2, 0, 10])
 @pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384), (130, 32768),
-                                 (70, 65536), (40, 131072)])
+                                 (70, 65536), (40, 131072),
+                                 # ragged n: the next shape up with the surplus lanes masked
+                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000)])
 def test_fused_step_equals_two_launch_step(m, n, variant):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -91,14 +93,15 @@ def test_fused_step_with_the_logistic_loss_equals_two_launch_step(m, n):
 
 
 def test_unsupported_shape_reports_and_auto_falls_back():
-    A = np.random.RandomState(0).randn(20, 300)
+    n = 131072 + 16                                # a row no longer fits 16 members x 16 pieces x 256 lanes
+    A = np.random.RandomState(0).randn(3, n) / 400
     op = fa.DenseMatrixMap(A)
     try:
         assert not op.ctx.fused_supported()
-        ls, reg = fa.LeastSquares(np.ones(20)), fa.Shrink(0.1)
+        ls, reg = fa.LeastSquares(np.ones(3)), fa.Shrink(0.1)
         with pytest.raises(ValueError):
-            fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(300), verbose=False, fused=True, max_iters=2)
-        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(300), verbose=False, max_iters=2, tolerance=0.0)
+            fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=True, max_iters=2)
+        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, max_iters=2, tolerance=0.0)
         assert c.iteration_count == 2
     finally:
         op.close()
