@@ -801,6 +801,9 @@ struct FusedIO {
   const double* x0; const double* g0; double* xhat; double* xp; double* z; double* g1;
   int kind;     // prox kind (FH_PROX_IDENTITY with tau = 0 gives the plain pair z = A x0, g1 = A^T grad f(z))
   int mode;     // 0 = with the n-side epilogue, 2 = g1 (+ loss) only
+  // FISTA (zero-initialised = off): x1 = xp + c*(xp - xacc0), gradient at z + c*(z - zacc0), c = coef or 0 after a restart
+  int accel = 0, restart = 0; double coef = 0.0;
+  const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr;
 };
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
@@ -814,8 +817,9 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.b = c->b; p.z = io.z; p.tau = tau; p.loss = c->loss_kind; p.mode = io.mode;
   p.px = make_prox(c, tau);
   p.px.kind = io.kind;
+  p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1;
   const unsigned grid = p.nteams * sh.team;
-  const size_t slots_elems = (size_t)c->mp * sh.team;
+  const size_t slots_elems = ((size_t)c->mp + p.nteams) * sh.team;      // + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
   FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
@@ -1049,6 +1053,23 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
     io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
     FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ));
   }
+  return fetch_scalars(c, scalars);
+}
+
+// One-pass iteration WITH acceleration (fasta/__init__.py:220-248): the launch computes this step's restart dot before
+// its first row, applies `coef` unless (restart != 0 and the dot > 1e-30, :231) and reports the dot in FH_S_RDOT so that
+// the caller can update alpha the same way.  Dense operator, single GPU (a row-sharded run would need the dot all-reduced
+// before the first row).
+extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  if (c->op != OP_DENSE) return fail(FH_E_STATE, "fh_step_accel: dense operator only");
+  if (c->comm) return fail(FH_E_STATE, "fh_step_accel: not available on a row-sharded operator (use fh_fwd + fh_adj)");
+  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
+  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], c->G[c->gc ^ 1], c->prox_kind, 0};
+  fio.accel = 1; fio.restart = restart ? 1 : 0; fio.coef = coef;
+  fio.xacc0 = c->P[c->pc]; fio.zacc0 = c->Z[c->zc]; fio.x1 = c->X[c->ti];
+  FH_TRY(launch_fused_dense(c, tau, fio));
+  c->last_accel = true;
   return fetch_scalars(c, scalars);
 }
 

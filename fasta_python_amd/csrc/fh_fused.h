@@ -33,8 +33,8 @@
 //
 // Used speculatively by the host driver (solver.py): the launch assumes the step will be accepted; if the
 // backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj as usual (identical
-// results either way).  Requires no acceleration (the FISTA coefficient depends on this launch's own
-// restart dot) and n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
+// results either way).  With acceleration (p.accel, fh_step_accel) the FISTA coefficient depends on this launch's own
+// restart dot: every team exchanges it through one extra slot line before its first row.  Requires n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
 // address, carry x = 0 and are masked out of every store (fasta_hip.hip:fused_shape picks the next shape up).
 #pragma once
 #include "fh_dense.h"
@@ -87,7 +87,12 @@ struct FusedP {
   int loss;
   int mode;              // 0 = full epilogue, 2 = row-sharded (g1 partial + local loss only)
   ProxP px;
-  double* slots;         // [mp][8] partial dot products, pre-filled with the sentinel
+  // FISTA (fasta/__init__.py:220-243): accel != 0 => x1 = xp + c*(xp - xacc0), the gradient is taken at z1 + c*(z1 - zacc0);
+  // c = coef unless restart != 0 and this step's restart dot <(x0 - xp), (xp - xacc0)> exceeds 1e-30 (:231), then 0.
+  int accel, restart;
+  double coef;
+  const double* xacc0; const double* zacc0; double* x1;
+  double* slots;         // [mp + nteams][TEAM] partial dot products (last nteams lines: restart dot), pre-filled with the sentinel
   double* gpart;         // [nteams][ld]
   double* g1;
   double* red;           // [grid][16] reduction partials
@@ -115,13 +120,15 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
   d2 xq[PPT];
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax, (rdot unused: no acceleration here)
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax (team 0 only); [6]: restart dot (every team)
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const uint32_t c = c0 + k * FH_WG;
     const uint32_t cl = min(c, p.ld2 - 1u);          // lanes past the row's last piece re-read it (results masked out)
     const d2 x0v = reinterpret_cast<const d2*>(p.x0)[cl];
     const d2 g0v = reinterpret_cast<const d2*>(p.g0)[cl];
+    d2 xav = {0.0, 0.0};
+    if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[cl];
     d2 xh, xp;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       double xpe = prox_scalar<KIND>(xhe, p.px, level);
       if (!valid) { xhe = 0.0; xpe = 0.0; }
       xh[e] = xhe; xp[e] = xpe;
+      if (valid) v[6] = fma(sub_nofma(x0v[e], xpe), sub_nofma(xpe, xav[e]), v[6]);
       if (valid && team == 0) {
         const double dx = sub_nofma(xpe, x0v[e]);
         const double dh = sub_nofma(xpe, xhe);
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   d2 ga[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
-  double fs = 0.0;
+  double fs = 0.0, fsa = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
 #ifdef FT_PROFILE
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // trip.  Measured hand-off (scripts/bench_mem/handoff.hip): sc1 store -> s_load glc ~0.5 us within and across
   // XCDs, sc1 store -> sc1 vector load 0.6-0.9 us.  The loop itself is plain C around the asm load: it contains no
   // compiler-visible vector memory operation, so hipcc's vmcnt bookkeeping for the row buffers stays exact.
-  auto poll_row = [&](uint32_t r, bool live) -> double {
+  auto poll_line = [&](uint32_t gl, bool live) -> double {     // gl: slot-line number = row of A (or mp + team)
     typedef unsigned ft_line __attribute__((ext_vector_type(16)));
     constexpr int NL = TEAM / 8;                   // 64-byte slot lines per row
     ft_line line[NL];
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) line[l][j] = 0u;
     if (live && !dead) {
-      const double* lp = p.slots + (uint64_t)grow(r) * TEAM;
+      const double* lp = p.slots + (uint64_t)gl * TEAM;
       unsigned cnt = 0u;
       for (;;) {
         if (NL == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
@@ -251,6 +259,23 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       ga[k].y = fma(buf[k].y, rv, ga[k].y);
     }
   };
+  // ---------------- FISTA: every team needs this step's restart dot before its first row (the gradient is taken at the
+  // extrapolated z): the members exchange their slice sums through the team's extra slot line, summed in member order
+  double coef = 0.0, rdot = 0.0;
+  if (p.accel) {
+    double w1[1] = {v[6]};
+    block_reduce<1>(w1, s_scr, 1);
+    if (tid == 0) store_partial(p.slots + (uint64_t)(p.mp + team) * TEAM + mem, w1[0]);
+    if (wave == 0) {
+      const double t = poll_line(p.mp + team, true);
+      if (lane == 0) s_bc[1] = t;
+    }
+    ft_lds_barrier();
+    rdot = s_bc[1];
+    coef = (p.restart && rdot > 1E-30) ? 0.0 : p.coef;
+  }
+  const auto* zq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.zacc0;   // z_accel0 (only read when accel)
+
   // b[r] through the scalar cache (constant address space => s_load, counted by lgkmcnt): as a vector load inside a
   // lane-0 branch it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
   const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
@@ -260,6 +285,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
       load_row(nbuf, min(nr, r_last));
       const double bi = bq[grow(r)];
+      const double za = p.accel ? zq[grow(r)] : 0.0;
       FT_T(0);
       const double part = dot_row(buf);
       FT_T(1);
@@ -269,10 +295,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       if (wave == 0) {
         post_row(r, true);
         FT_T(3);
-        const double zs = poll_row(r, true);
+        const double zs = poll_line(grow(r), true);
         FT_T(4);
         if (lane == 0) {
-          s_bc[0] = loss_grad(zs, bi, p.loss);
+          s_bc[0] = loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss);
           if (mem == 0) store_partial(p.z + grow(r), zs);              // read back below by other lanes of this workgroup
         }
       }
@@ -325,6 +351,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           const uint32_t r = r_begin + t + j;
           const bool live = r < r_end;
           const double bi = bq[grow(min(r, r_last))];
+          const double za = p.accel ? zq[grow(min(r, r_last))] : 0.0;
           load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
           FT_T(0);
           const double d = dot_row(B[(j + D) % NB]);
@@ -333,10 +360,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           ft_lds_barrier();                                        // wave 1 posts row r+D from s_part[0..3]
           FT_T(2);
           FT_T(3);
-          const double zs = poll_row(r, live);
+          const double zs = poll_line(grow(min(r, r_last)), live);
           FT_T(4);
           if (lane == 0) {
-            s_bc[0] = live ? loss_grad(zs, bi, p.loss) : 0.0;
+            s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
             if (mem == 0 && live) store_partial(p.z + grow(r), zs);
           }
           FT_T(5);
@@ -387,7 +414,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     __syncthreads();
     for (uint32_t i = tid; i < r_end; i += FH_WG) {
       const uint32_t r = grow(i);
-      if (r < p.m) fs += loss_term(load_partial(p.z + r), bq[r], p.loss);
+      if (r < p.m) {
+        const double zr = load_partial(p.z + r);
+        fs += loss_term(zr, bq[r], p.loss);
+        if (p.accel) fsa += loss_term(extrapolate(zr, p.zacc0[r], coef), bq[r], p.loss);   // f at the extrapolated point (:245)
+      }
     }
   }
 
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   for (int k = 0; k < PPT; ++k)
     if (c0 + k * FH_WG < p.ld2) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
   {
-    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], 0.0};
+    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], fsa};
     block_reduce<8>(w, s_scr, 6);
     if (tid == 0) {
 #pragma unroll
@@ -422,7 +453,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 
   // ---------------- every workgroup finalises its share of the columns: team-ordered sum + n-side epilogue ----
   AdjP e;                                            // reuse K-adj's per-element epilogue
-  e.accel = 0; e.coef = 0.0; e.tau = p.tau;
+  e.accel = p.accel; e.coef = coef; e.tau = p.tau;
   double u[5] = {0, 0, 0, 0, 0};                     // dxdg, dg2, xh2, gsum, gmax
   const uint32_t share = (p.ld2 + gridDim.x - 1) / gridDim.x;
   for (uint32_t t = tid; t < share; t += FH_WG) {
@@ -438,8 +469,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
       const d2 xpv = load_partial2(reinterpret_cast<const d2*>(p.xp) + c);
       const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
-      bb_element(e, g.x, x0v.x, xpv.x, 0.0, xhv.x, 2u * c < p.n, u);
-      bb_element(e, g.y, x0v.y, xpv.y, 0.0, xhv.y, 2u * c + 1u < p.n, u);
+      d2 xav = {0.0, 0.0};
+      if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[c];
+      d2 x1v;
+      x1v.x = bb_element(e, g.x, x0v.x, xpv.x, xav.x, xhv.x, 2u * c < p.n, u);
+      x1v.y = bb_element(e, g.y, x0v.y, xpv.y, xav.y, xhv.y, 2u * c + 1u < p.n, u);
+      if (p.accel) reinterpret_cast<d2*>(p.x1)[c] = x1v;
     }
   }
   block_reduce<5>(u, s_scr, 4);
@@ -457,15 +492,15 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   }
   {
-    double a[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], 0.0};
+    double a[8] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
     block_reduce<8>(a, s_scr, 6);
     double bq[5] = {w[8], w[9], w[10], w[11], w[12]};
     block_reduce<5>(bq, s_scr, 4);
     if (tid == 0) {
       p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
-      p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = 0.0;
+      p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = rdot;   // every team computed the same restart dot
       p.out[S_DXDG] = bq[0]; p.out[S_DG2] = bq[1]; p.out[S_XH2_ADJ] = bq[2]; p.out[S_GSUM_ADJ] = bq[3];
-      p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = a[0];
+      p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = p.accel ? a[7] : a[0];
       p.out[S_ALPHA] = level;
       p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
     }

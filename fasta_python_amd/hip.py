@@ -54,6 +54,7 @@ SIGNATURES = {
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_step": (_i32, [_ctx, _dbl, _pd]),
+    "fh_step_accel": (_i32, [_ctx, _dbl, _dbl, _i32, _pd]),
     "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
     "fh_comm_unique_id": (_i32, [C.c_void_p]),
     "fh_comm_init": (_i32, [_ctx, _i32, _i32, C.c_void_p]),
@@ -224,6 +225,14 @@ class HipContext:
     def step(self, tau):
         """One-pass K-fwd + K-adj (no acceleration).  Raises if the bounded spins timed out."""
         self._call("fh_step", float(tau), self._scal_p)
+        if self._scal[15] != 0.0:
+            raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
+        return self._scal.copy()
+
+    def step_accel(self, tau, coef, restart):
+        """One-pass K-fwd + K-adj with FISTA extrapolation: `coef` applies unless `restart` and this step's restart
+        dot (returned in S_RDOT) exceeds 1e-30.  Dense operator, single GPU."""
+        self._call("fh_step_accel", float(tau), float(coef), 1 if restart else 0, self._scal_p)
         if self._scal[15] != 0.0:
             raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()

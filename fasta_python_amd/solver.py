@@ -95,9 +95,10 @@ class FBSolver:
                  stepsize_shrink=None, window=10, max_backtracks=20, restart=True, evaluate_objective=False,
                  record_iterates=False, func=None, *, fused="auto"):
         """Reference options (fasta/__init__.py:42-53) plus one build-only, keyword-only switch:
-        fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step`, csrc/fh_fused.h) when the
-        operator shape supports it and acceleration is off.  It is speculative: the launch assumes the step is
-        accepted; when the backtracking test fails the iteration falls back to K-fwd/K-adj (same results)."""
+        fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step` / `step_accel`, csrc/fh_fused.h)
+        when the operator shape supports it (with acceleration: dense operator on one GPU).  It is speculative: the
+        launch assumes the step is accepted; when the backtracking test fails the iteration falls back to
+        K-fwd/K-adj (same results)."""
         self.A, self.loss, self.prox = A, loss, prox
         self.fused_opt = fused
         self.ctx = A.ctx
@@ -160,15 +161,17 @@ class FBSolver:
         if self.func:                                                   # :149-151
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
-        kind = c.fused_supported() if (self.fused_opt is not False and not self.accelerate) else 0
+        kind = c.fused_supported() if self.fused_opt is not False else 0
         if kind == 3 and self.fused_opt is not True:        # available but slower than two launches at this size
             kind = 0
+        if self.accelerate and (kind == 2 or getattr(c, "sharded", False)):
+            kind = 0        # FISTA in one pass: dense operator on one GPU only (the restart dot precedes the first row)
         self.use_fused = kind != 0
         # dense: speculative (a rejected step wastes the A^T half, so back off after backtracks);
         # stencil: the one-pass kernel costs no more than K-fwd alone, so it also serves the backtracking retries
         self.fused_always = kind == 2
         if self.fused_opt is True and not self.use_fused:
-            raise ValueError("fused=True needs accelerate=False and a stencil operator or a dense one with n <= 131072")
+            raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator without acceleration")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
         self.alpha1 = 1.0                                               # :157
@@ -190,7 +193,11 @@ class FBSolver:
         a = None
         if self.use_fused and (self.fused_always or self._spec_cooldown == 0):
             try:
-                s = c.step(tau)                                         # one pass over A: K-fwd and K-adj together
+                if self.accelerate:     # the launch decides the restart itself (:231); the host mirrors it below
+                    a1 = (1 + np.sqrt(1 + 4 * self.alpha1 ** 2)) / 2
+                    s = c.step_accel(tau, (self.alpha1 - 1) / a1, self.restart)
+                else:
+                    s = c.step(tau)                                     # one pass over A: K-fwd and K-adj together
                 a = s
                 self.fused_steps += 1
             except hip.HipError as exc:                                 # bounded-spin timeout: never speculate again

@@ -30,6 +30,10 @@ for rnd in range(2):
         t = timed(lambda: ctx.step(0.2), hip.K_FUSED)
         print(f"round {rnd} variant {variant} (defer={variant & 1} xcd={(variant >> 1) & 1} prefetch_deferred={variant & 1}): "
               f"{t:7.3f} ms  moves {m * n * 8 / t / 1e6:6.0f} GB/s  algorithmic {2 * m * n * 8 / t / 1e6:6.0f} GB/s", flush=True)
+ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2)
+ctx.step(0.2); ctx.commit()
+t = timed(lambda: ctx.step_accel(0.2, 0.4, True), hip.K_FUSED)
+print(f"accelerated one-pass step: {t:7.3f} ms", flush=True)
 tf = timed(lambda: ctx.fwd(0.2), hip.K_FWD)
 ta = timed(lambda: ctx.adj(0.2), hip.K_ADJ)
 print(f"two-launch: fwd {tf:.3f} + adj {ta:.3f} = {tf + ta:.3f} ms")

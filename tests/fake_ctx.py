@@ -145,6 +145,15 @@ class FakeContext:
         self.calls["adj"] -= 1
         return s
 
+    def step_accel(self, tau, coef, restart):
+        self.calls["step"] += 1
+        s = self.fwd(tau)
+        self.calls["fwd"] -= 1
+        applied = 0.0 if (restart and s[hip.S_RDOT] > 1E-30) else coef      # the launch's own restart rule (:231)
+        a = self.adj(tau, True, applied)
+        self.calls["adj"] -= 1
+        return a
+
     def commit(self, save_best=False):
         self.xacc, self.z_acc = self.xp, self.z1          # FISTA history (pre-extrapolation values)
         self.x0, self.g0 = self.x1, self.g1

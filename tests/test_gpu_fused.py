@@ -92,6 +92,49 @@ def test_fused_step_with_the_logistic_loss_equals_two_launch_step(m, n):
         op.close()
 
 
+@pytest.mark.parametrize("loss", ["lsq", "logistic"])
+@pytest.mark.parametrize("m,n,restart", [(300, 4096, True), (300, 4096, False), (64, 65536, True), (90, 20000, True), (2500, 8192, False)])
+def test_fused_accelerated_step_equals_two_launch_step(m, n, restart, loss):
+    """fh_step_accel: restart dot before the first row, gradient at the extrapolated z, x1 extrapolated (FISTA)."""
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = np.where(rng.rand(m) < 0.5, 1.0, -1.0) if loss == "logistic" else rng.randn(m)
+    x0 = rng.randn(n) * 0.05
+    tau, mu = 0.4, 0.03
+    op = fa.DenseMatrixMap(A)
+    try:
+        c = op.ctx
+
+        def warm():        # one committed accelerated iteration, so that x_accel0 / z_accel0 differ from x0 / z0
+            (c.set_loss_logistic if loss == "logistic" else c.set_loss_lsq)(b)
+            c.set_prox(hip.PROX_SHRINK, mu); c.set_vector(hip.VEC_X0, x0); c.init()
+            c.fwd(tau); c.adj(tau, True, 0.0); c.commit()
+            c.fwd(tau); c.adj(tau, True, 0.28); c.commit()
+
+        coef = 0.43
+        warm()
+        s = c.fwd(tau)
+        applied = 0.0 if (restart and s[hip.S_RDOT] > 1e-30) else coef
+        a = c.adj(tau, True, applied)
+        ref = {k: c.get_vector(k, n) for k in (hip.VEC_XHAT, hip.VEC_XPROX, hip.VEC_X1, hip.VEC_G1)}
+        zref = c.get_vector(hip.VEC_Z, m)
+        warm()
+        f = c.step_accel(tau, coef, restart)
+        np.testing.assert_allclose(f[hip.S_RDOT], s[hip.S_RDOT], rtol=1e-9, atol=1e-18)
+        assert (f[hip.S_RDOT] > 1e-30) == (s[hip.S_RDOT] > 1e-30)
+        for k in (hip.S_FSQ, hip.S_DXG0, hip.S_DX2, hip.S_XH2, hip.S_G02, hip.S_GSUM, hip.S_GMAX):
+            np.testing.assert_allclose(f[k], s[k], rtol=1e-12, atol=1e-300, err_msg=f"fwd scalar {k}")
+        for k in (hip.S_DXDG, hip.S_DG2, hip.S_FSQ_ADJ, hip.S_XH2_ADJ, hip.S_GSUM_ADJ, hip.S_GMAX_ADJ):
+            np.testing.assert_allclose(f[k], a[k], rtol=1e-10, atol=1e-18, err_msg=f"adj scalar {k}")
+        assert np.array_equal(c.get_vector(hip.VEC_XHAT, n), ref[hip.VEC_XHAT])
+        assert np.array_equal(c.get_vector(hip.VEC_XPROX, n), ref[hip.VEC_XPROX])
+        assert np.array_equal(c.get_vector(hip.VEC_X1, n), ref[hip.VEC_X1])
+        np.testing.assert_allclose(c.get_vector(hip.VEC_Z, m), zref, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), ref[hip.VEC_G1], rtol=1e-10, atol=1e-15)
+    finally:
+        op.close()
+
+
 def test_unsupported_shape_reports_and_auto_falls_back():
     n = 131072 + 16                                # a row no longer fits 16 members x 16 pieces x 256 lanes
     A = np.random.RandomState(0).randn(3, n) / 400
@@ -107,7 +150,7 @@ def test_unsupported_shape_reports_and_auto_falls_back():
         op.close()
 
 
-@pytest.mark.parametrize("kind", ["shrink", "nonneg", "backtracking"])
+@pytest.mark.parametrize("kind", ["shrink", "nonneg", "backtracking", "accelerated", "accelerated_norestart"])
 def test_full_solve_with_fused_steps_matches_oracle(kind):
     rng = np.random.RandomState(5)
     m, n = 700, 4096
@@ -119,6 +162,8 @@ def test_full_solve_with_fused_steps_matches_oracle(kind):
     opts = dict(tolerance=1e-6, max_iters=80, evaluate_objective=True, record_iterates=True)
     if kind == "backtracking":
         opts.update(L=1.0, tau0=1.0, max_iters=40, tolerance=0.0)     # unnormalised A: forces backtracks -> fallback path
+    if kind.startswith("accelerated"):
+        opts.update(adaptive=False, accelerate=True, restart=kind == "accelerated", max_iters=120)
     mu = 0.02
     reg = fa.NonNeg() if kind == "nonneg" else fa.Shrink(mu)
     P = pr.nn_least_squares_from(A, b) if kind == "nonneg" else pr.sparse_least_squares_from(A, b, mu)
