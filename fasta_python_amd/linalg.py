@@ -123,6 +123,37 @@ class _DeviceMap(LinearMap):
     def close(self):
         self.ctx.close()
 
+    def spectral_norm_squared(self, iters=50, rtol=1e-6, seed=None):
+        """||A||_2^2 by power iteration on A^H A, the matvecs running on the device: each iteration is one
+        `fh_gradient_at` with a zero target (the one-pass kernel reads a dense A once for both directions); the host only
+        normalises the n-vector in between.  OPT-IN replacement for `LinearMap.eigs` (linalg.py:149-160) and for the
+        four setup passes of fasta()'s random-probe estimate (fasta/__init__.py:100-113): for f = .5||Ax - b||^2 pass
+        `L = op.spectral_norm_squared()` and `tau0 = (2 / L) / 10` to fasta().  A different L changes every iterate with
+        respect to the reference's RNG-based estimate, so fasta() never calls this by itself.
+        Overwrites the context's loss with a zero least-squares target; call it before fasta() (which sets its own)."""
+        c = self.ctx
+        n = int(np.prod(self.Vshape))
+        m = int(np.prod(self.Wshape))
+        rng = np.random.RandomState(seed)
+        x = rng.randn(n)
+        x /= np.linalg.norm(x)
+        c.set_loss_lsq(np.zeros(m))
+        lam = 0.0
+        for _ in range(int(iters)):
+            c.set_vector(hip.VEC_T0, x)
+            c.gradient_at(hip.VEC_T0, hip.VEC_T1)                  # y = A^H (A x - 0)
+            y = c.get_vector(hip.VEC_T1, n)
+            new = float(np.dot(x, y))                              # Rayleigh quotient (||x|| = 1)
+            ny = float(np.linalg.norm(y))
+            if ny == 0.0:
+                return 0.0
+            x = y / ny
+            if abs(new - lam) <= rtol * abs(new):
+                lam = new
+                break
+            lam = new
+        return lam
+
 
 class DenseMatrixMap(_DeviceMap):
     """Dense float64 matrix held row-major in HBM (the operator of fasta/linalg.py:41).

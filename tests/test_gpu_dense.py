@@ -266,3 +266,25 @@ def test_c2_full_size_first_iterations_match_oracle_loop():
         np.testing.assert_allclose(getattr(got, f)[:iters], getattr(want, f)[:iters], rtol=1e-8, err_msg=f)
     np.testing.assert_allclose(got.objectives[:iters + 1], want.objectives[:iters + 1], rtol=1e-8)
     np.testing.assert_allclose(got.iterates[:iters + 1], want.iterates[:iters + 1], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(300, 500), (64, 20000), (2000, 16384)])
+def test_on_device_spectral_norm_matches_numpy(shape):
+    """Opt-in Lipschitz estimate: power iteration on A^H A with device matvecs."""
+    rng = np.random.RandomState(shape[0])
+    A = rng.randn(*shape) / 10
+    A += np.outer(rng.randn(shape[0]), rng.randn(shape[1])) / 40       # a clear top singular value: power iteration converges fast
+    op = fa.DenseMatrixMap(A)
+    try:
+        L = op.spectral_norm_squared(iters=200, rtol=1e-13, seed=0)
+        want = np.linalg.norm(A, 2) ** 2
+        np.testing.assert_allclose(L, want, rtol=1e-8)
+        assert op.spectral_norm_squared(iters=5, seed=1) <= want * (1 + 1e-12)      # a Rayleigh quotient never overshoots
+        # and it is usable as fasta()'s L / tau0 (no RNG probes, fasta/__init__.py:100)
+        b = rng.randn(shape[0])
+        ls, reg = fa.LeastSquares(b), fa.Shrink(0.1)
+        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(shape[1]), verbose=False, L=L, tau0=(2 / L) / 10,
+                     max_iters=30, tolerance=0.0)
+        assert c.iteration_count == 30 and np.all(np.isfinite(c.residuals[:30]))
+    finally:
+        op.close()
