@@ -779,21 +779,12 @@ static FusedShape fused_shape(fh_ctx* c) {
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 
-template <int PPT, int KIND, int PIPE, int TEAM>
-static void launch_fused_k(fh_ctx* c, const FusedP& p, unsigned grid) {
-  // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
-  k_fused_dense<PPT, 1, KIND, PIPE, TEAM><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-}
+// the prox kind travels in p.px.kind (run-time switch in the kernel's n-side prologue); FH_PROX_* == PX_* numerically
 template <int PPT, int PIPE, int TEAM>
 static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) {
-  switch (kind) {
-    case FH_PROX_SHRINK: launch_fused_k<PPT, PX_SHRINK, PIPE, TEAM>(c, p, grid); break;
-    case FH_PROX_NONNEG: launch_fused_k<PPT, PX_NONNEG, PIPE, TEAM>(c, p, grid); break;
-    case FH_PROX_LINF:   launch_fused_k<PPT, PX_LINF, PIPE, TEAM>(c, p, grid); break;
-    case FH_PROX_L1BALL: launch_fused_k<PPT, PX_L1BALL, PIPE, TEAM>(c, p, grid); break;
-    case FH_PROX_BOX:    launch_fused_k<PPT, PX_BOX, PIPE, TEAM>(c, p, grid); break;
-    default:             launch_fused_k<PPT, PX_IDENTITY, PIPE, TEAM>(c, p, grid); break;
-  }
+  (void)kind;
+  // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
+  k_fused_dense<PPT, 1, PIPE, TEAM><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 
 // operands of one fused launch; fh_step takes them from the solver state, fh_init / fh_gradient_at pass their own

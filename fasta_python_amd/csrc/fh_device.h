@@ -52,6 +52,18 @@ __device__ __forceinline__ double prox_scalar(double x, const ProxP& px, double 
   return x;
 }
 
+// same, kind chosen at run time (kernels that evaluate the prox once per launch)
+__device__ __forceinline__ double prox_scalar_rt(int kind, double x, const ProxP& px, double level) {
+  switch (kind) {
+    case PX_SHRINK: return prox_scalar<PX_SHRINK>(x, px, level);
+    case PX_NONNEG: return prox_scalar<PX_NONNEG>(x, px, level);
+    case PX_BOX:    return prox_scalar<PX_BOX>(x, px, level);
+    case PX_LINF:   return prox_scalar<PX_LINF>(x, px, level);
+    case PX_L1BALL: return prox_scalar<PX_L1BALL>(x, px, level);
+    default:        return x;
+  }
+}
+
 // forward (gradient) step x0 - tau*g0, two roundings as in fasta/__init__.py:181
 __device__ __forceinline__ double fwd_point(double x0, double g0, double tau) {
 #pragma clang fp contract(off)

@@ -106,7 +106,7 @@ __device__ __forceinline__ bool ft_is_sentinel(double v) {
   return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
 }
 
-template <int PPT, int NT, int KIND, int PIPE, int TEAM>
+template <int PPT, int NT, int PIPE, int TEAM>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
@@ -116,7 +116,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   const uint32_t team = (p.variant & 2) ? blockIdx.x % p.nteams : blockIdx.x / TEAM;
   const uint32_t mem = (p.variant & 2) ? blockIdx.x / p.nteams : blockIdx.x % TEAM;
   const uint32_t c0 = mem * (FH_WG * PPT) + tid;                // first 16-byte piece of this lane; next at +256
-  const double level = (KIND == PX_LINF || KIND == PX_L1BALL) ? *p.px.level : 0.0;
+  // the prox runs once per launch (n-side prologue), so its kind is a run-time switch here (K-fwd recomputes it per row
+  // group and keeps it a template parameter)
+  const int kind = p.px.kind;
+  const double level = (kind == PX_LINF || kind == PX_L1BALL) ? *p.px.level : 0.0;
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
   d2 xq[PPT];
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     for (int e = 0; e < 2; ++e) {
       const bool valid = (2u * c + e) < p.n;
       double xhe = fwd_point(x0v[e], g0v[e], p.tau);
-      double xpe = prox_scalar<KIND>(xhe, p.px, level);
+      double xpe = prox_scalar_rt(kind, xhe, p.px, level);
       if (!valid) { xhe = 0.0; xpe = 0.0; }
       xh[e] = xhe; xp[e] = xpe;
       if (valid) v[6] = fma(sub_nofma(x0v[e], xpe), sub_nofma(xpe, xav[e]), v[6]);
