@@ -167,9 +167,11 @@ class FBSolver:
         if self.accelerate and (kind == 2 or getattr(c, "sharded", False)):
             kind = 0        # FISTA in one pass: dense operator on one GPU only (the restart dot precedes the first row)
         self.use_fused = kind != 0
-        # dense: speculative (a rejected step wastes the A^T half, so back off after backtracks);
-        # stencil: the one-pass kernel costs no more than K-fwd alone, so it also serves the backtracking retries
-        self.fused_always = kind == 2
+        # Where the one-pass kernel costs no more than K-fwd alone -- the stencil, and the dense operator from n = 16384
+        # (kind 1: 65536^2 5.0 ms vs K-fwd 4.9 ms) -- it also serves the backtracking retries.  A dense operator below
+        # that (kind 3, only with fused=True) uses it speculatively and backs off after a backtrack: there a rejected
+        # step wastes the A^T half.
+        self.fused_always = kind in (1, 2)
         if self.fused_opt is True and not self.use_fused:
             raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator without acceleration")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
@@ -182,6 +184,25 @@ class FBSolver:
         self.done = False
         return self
 
+    def _forward(self, tau, one_pass):
+        """(fwd scalars, adj scalars or None): the one-pass kernel when enabled and asked for, else K-fwd alone."""
+        c = self.ctx
+        if self.use_fused and one_pass:
+            try:
+                if self.accelerate:     # the launch decides the restart itself (:231); step() mirrors it afterwards
+                    a1 = (1 + np.sqrt(1 + 4 * self.alpha1 ** 2)) / 2
+                    s = c.step_accel(tau, (self.alpha1 - 1) / a1, self.restart)
+                else:
+                    s = c.step(tau)
+                self.fused_steps += 1
+                return s, s
+            except hip.HipError as exc:                                 # bounded-spin timeout: never use it again
+                if getattr(c, "sharded", False):
+                    raise       # ranks cannot fall back independently: their collective sequences would diverge
+                warnings.warn(f"fused one-pass kernel disabled: {exc}")
+                self.use_fused = False
+        return c.fwd(tau), None
+
     # ------------------------------------------------------------------------------------------
     def step(self):
         """One FBS iteration (fasta/__init__.py:171-312).  Returns True when the stop rule fires."""
@@ -190,25 +211,10 @@ class FBSolver:
         tau = self.tau_next                                             # :178
 
         fval = self._fval
-        a = None
-        if self.use_fused and (self.fused_always or self._spec_cooldown == 0):
-            try:
-                if self.accelerate:     # the launch decides the restart itself (:231); the host mirrors it below
-                    a1 = (1 + np.sqrt(1 + 4 * self.alpha1 ** 2)) / 2
-                    s = c.step_accel(tau, (self.alpha1 - 1) / a1, self.restart)
-                else:
-                    s = c.step(tau)                                     # one pass over A: K-fwd and K-adj together
-                a = s
-                self.fused_steps += 1
-            except hip.HipError as exc:                                 # bounded-spin timeout: never speculate again
-                if getattr(c, "sharded", False):
-                    raise       # ranks cannot fall back independently: their collective sequences would diverge
-                warnings.warn(f"fused one-pass kernel disabled: {exc}")
-                self.use_fused = False
-                s = c.fwd(tau)
-        else:
-            s = c.fwd(tau)                                              # :181-188  (K-fwd)
-            self._spec_cooldown = max(self._spec_cooldown - 1, 0)
+        speculate = self.fused_always or self._spec_cooldown == 0
+        s, a = self._forward(tau, speculate)                            # :181-188  (K-fwd, or K-fwd + K-adj in one pass)
+        if not speculate:
+            self._spec_cooldown -= 1
         f1 = fval(s[hip.S_FSQ])
         bt = 0
         if self.backtrack:                                              # :195-217
@@ -216,12 +222,9 @@ class FBSolver:
             while (f1 - (M + s[hip.S_DXG0] + np.sqrt(s[hip.S_DX2]) ** 2 / (2 * tau)) > EPSILON
                    and bt < self.max_backtracks):
                 tau *= self.stepsize_shrink
-                if self.use_fused and self.fused_always:
-                    s = a = c.step(tau)                                 # stencil: one-pass kernel again
-                    self.fused_steps += 1
-                else:
-                    s = c.fwd(tau)                                      # :207-213  (K-fwd again)
-                    a = None                                            # a speculative K-adj (if any) is void
+                # :207-213: K-fwd again (a speculative K-adj, if any, is void) -- or the one-pass kernel again where it
+                # costs what K-fwd costs
+                s, a = self._forward(tau, self.fused_always)
                 f1 = fval(s[hip.S_FSQ])
                 bt += 1
             self.total_backtracks += bt

@@ -150,17 +150,17 @@ def test_unsupported_shape_reports_and_auto_falls_back():
         op.close()
 
 
-@pytest.mark.parametrize("kind", ["shrink", "nonneg", "backtracking", "accelerated", "accelerated_norestart"])
+@pytest.mark.parametrize("kind", ["shrink", "nonneg", "backtracking", "accelerated", "accelerated_norestart", "backtracking_n16384"])
 def test_full_solve_with_fused_steps_matches_oracle(kind):
     rng = np.random.RandomState(5)
-    m, n = 700, 4096
+    m, n = (300, 16384) if kind == "backtracking_n16384" else (700, 4096)
     A = rng.randn(m, n)
-    if kind != "backtracking":
+    if not kind.startswith("backtracking"):
         A /= np.linalg.norm(A, 2)
     x_true = np.zeros(n); x_true[rng.permutation(n)[:20]] = 1
     b = A @ x_true + 0.01 * rng.randn(m)
     opts = dict(tolerance=1e-6, max_iters=80, evaluate_objective=True, record_iterates=True)
-    if kind == "backtracking":
+    if kind.startswith("backtracking"):
         opts.update(L=1.0, tau0=1.0, max_iters=40, tolerance=0.0)     # unnormalised A: forces backtracks -> fallback path
     if kind.startswith("accelerated"):
         opts.update(adaptive=False, accelerate=True, restart=kind == "accelerated", max_iters=120)
@@ -184,8 +184,10 @@ def test_full_solve_with_fused_steps_matches_oracle(kind):
     assert solver.fused_steps > 0
     assert got.iteration_count == want.iteration_count == two.iteration_count
     assert got.backtracks == want.backtracks == two.backtracks
-    if kind == "backtracking":
+    if kind == "backtracking":          # n = 4096: speculative use, abandoned for the retries and the cool-down iterations
         assert got.backtracks > 0 and solver.fused_steps < got.iteration_count
+    if kind == "backtracking_n16384":   # from n = 16384 the one-pass kernel also serves every backtracking retry
+        assert got.backtracks > 0 and solver.fused_steps == got.iteration_count + got.backtracks
     k = got.iteration_count
     rtol = 1e-6
     for f in ("residuals", "norm_residuals", "stepsizes"):

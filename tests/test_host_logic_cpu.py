@@ -15,7 +15,7 @@ from tests.gpu_util import TAGS
 CASES = [n for n in H.golden_cases() if not n.startswith("c1_")]
 
 
-def _run(name, fused):
+def _run(name, fused, dense_kind=1):
     meta, z = H.load_case(name)
     data = H.case_data(meta, z)
     kind = meta["kind"]
@@ -23,7 +23,7 @@ def _run(name, fused):
         A = FakeStencilMap(data["M"].shape, fused_kind=2 if fused else 0)
         loss, x0 = fa.LeastSquares(data["M"] / float(data["mu"])), np.zeros(data["M"].shape + (2,))
     else:
-        A = FakeDenseMap(data["A"], fused_kind=1 if fused else 0)
+        A = FakeDenseMap(data["A"], fused_kind=dense_kind if fused else 0)
         loss = fa.LogisticLoss(data["b"]) if kind == "logistic" else fa.LeastSquares(data["b"])
         x0 = np.zeros(data["A"].shape[1])
     reg = TAGS[kind](data)
@@ -32,14 +32,17 @@ def _run(name, fused):
     np.random.seed(meta["solver_seed"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        c = fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, fused="auto", **o)
+        # kind 3 (one-pass kernel available but not recommended at this size) is only used when forced
+        c = fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, fused=True if (fused and dense_kind == 3 and kind != "tv") else "auto", **o)
     return meta, z, c, A.ctx
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, 3])
 @pytest.mark.parametrize("name", CASES)
 def test_driver_reproduces_reference_run(name, fused):
-    meta, z, c, ctx = _run(name, fused)
+    """fused: False = two launches; True = one-pass kernel wherever it costs no more than K-fwd (also for the backtracking
+    retries); 3 = dense one-pass kernel used speculatively (sizes where a rejected step wastes the A^T half)."""
+    meta, z, c, ctx = _run(name, bool(fused), dense_kind=3 if fused == 3 else 1)
     long_chaotic = int(z["backtracks"]) > 50                       # SURVEY section 7: rounding is amplified there
     if not long_chaotic:
         assert c.iteration_count == int(z["iteration_count"])
@@ -56,14 +59,16 @@ def test_driver_reproduces_reference_run(name, fused):
     accelerated = bool(meta["options"].get("accelerate", False))
     if fused and not (accelerated and meta["kind"] == "tv"):       # FISTA in one pass: dense operator only
         assert ctx.calls["step"] > 0                               # the one-pass path was taken ...
-        if meta["kind"] != "tv" and c.backtracks:
+        if fused == 3 and meta["kind"] != "tv" and c.backtracks:
             assert ctx.calls["fwd"] > 0 and ctx.calls["adj"] > 0   # ... and abandoned for the backtracking retries
+        if fused is True:
+            assert ctx.calls["fwd"] == 0 and ctx.calls["adj"] == 0 # ... for every launch of the loop
     else:
         assert ctx.calls["step"] == 0
 
 
 def test_speculation_backs_off_after_a_backtrack():
-    meta, z, c, ctx = _run("sparse_ls_unnormalised_backtracks", True)
+    meta, z, c, ctx = _run("sparse_ls_unnormalised_backtracks", True, dense_kind=3)
     # 105 backtracks in 200 iterations: most iterations must have used the two-launch path
     assert ctx.calls["step"] < c.iteration_count // 2
 
