@@ -761,21 +761,28 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 //   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead; FH_TUNE_FUSED_VARIANT bit 8 and n = 65536:
 //                8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
 //   n <= 131072: 16 members x 16 pieces, exchange in line
+// Teams of 32 (n <= 131072 with posts two or three rows ahead, n <= 262144 in line) were built and measured: a trip costs
+// 1.65 us with 32 members, so they only tie the shapes above / the two-launch path (profiles/r01d_fused_tuning.txt).
 struct FusedShape { int ppt, team, pipe; };
 static FusedShape fused_shape(fh_ctx* c) {
   FusedShape none = {0, 0, 0};
-  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ncu < FT_TEAM_MAX || c->ncu % FT_TEAM_MAX) return none;
-  if (c->ld % 2 || c->n == 0) return none;
+  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ld % 2 || c->n == 0) return none;
   const uint64_t pieces = round_up(c->n, 16) / 2;    // 16-byte pieces per row that hold data (the row stride c->ld may be padded)
-  if (pieces > c->ld / 2 || pieces > (uint64_t)16 * FH_WG * 16) return none;
+  if (pieces > c->ld / 2) return none;
+  FusedShape sh = none;
   if (pieces <= (uint64_t)8 * FH_WG * 8) {
     int ppt = (int)((pieces + 8 * FH_WG - 1) / (8 * FH_WG));
     if (ppt == 3) ppt = 4;
-    return {ppt, 8, 1};
+    sh = {ppt, 8, 1};
+  } else if (pieces == (uint64_t)8 * FH_WG * 16 && (c->fused_variant & 8)) {
+    sh = {16, 8, 0};
+  } else if (pieces <= (uint64_t)16 * FH_WG * 8) {
+    sh = {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2};
+  } else if (pieces <= (uint64_t)16 * FH_WG * 16) {
+    sh = {16, 16, 0};
   }
-  if (pieces == (uint64_t)8 * FH_WG * 16 && (c->fused_variant & 8)) return {16, 8, 0};
-  if (pieces <= (uint64_t)16 * FH_WG * 8) return {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2};
-  return {16, 16, 0};
+  if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;     // one workgroup per CU, whole teams only
+  return sh;
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 
@@ -832,7 +839,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     }
   } else if (sh.team == 8) {
     launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
-  } else if (sh.pipe) {                      // 16 members: posts run two rows ahead of the polls
+  } else if (sh.team == 16 && sh.pipe) {       // 16 members: posts run two rows ahead of the polls
     switch (sh.ppt) {
       case 5: launch_fused_p<5, 2, 16>(c, p, grid, io.kind); break;
       case 6: launch_fused_p<6, 2, 16>(c, p, grid, io.kind); break;

@@ -39,7 +39,7 @@
 #pragma once
 #include "fh_dense.h"
 
-#define FT_TEAM_MAX 16                              // members per team: 8 or 16 (template parameter TEAM)
+#define FT_TEAM_MAX 16                              // members per team: 8 or 16 (template parameter TEAM; 32 works, see fused_shape)
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock (grid barrier)
 #define FT_SPIN_POLLS 1000000u                      // slot-poll budget: ~0.3-0.5 us per poll (s_load glc + s_sleep) => ~0.4 s
@@ -199,43 +199,67 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // trip.  Measured hand-off (scripts/bench_mem/handoff.hip): sc1 store -> s_load glc ~0.5 us within and across
   // XCDs, sc1 store -> sc1 vector load 0.6-0.9 us.  The loop itself is plain C around the asm load: it contains no
   // compiler-visible vector memory operation, so hipcc's vmcnt bookkeeping for the row buffers stays exact.
-  auto poll_line = [&](uint32_t gl, bool live) -> double {     // gl: slot-line number = row of A (or mp + team)
-    typedef unsigned ft_line __attribute__((ext_vector_type(16)));
-    constexpr int NL = TEAM / 8;                   // 64-byte slot lines per row
-    ft_line line[NL];
+  typedef unsigned ft_line __attribute__((ext_vector_type(16)));
+  constexpr int NL = TEAM / 8;                     // 64-byte slot lines per row
+  constexpr int LG = NL < 2 ? NL : 2;              // lines per poll: at most two (32 SGPRs); 32 members poll twice
+  // speculative read of the slot line(s) at the top of the trip: not for 8 members x 8 pieces, whose loop has no register left
+  // (measured: 32768^2 1.24 -> 1.30 ms with it, 8192 x 32768 0.71 -> 0.64 ms, 65536^2 5.05 -> 4.98 ms)
+  constexpr bool EARLY = PIPE != 0 && NL <= 2 && (PPT < 8 || TEAM >= 16);
+  // `pre` (EARLY): the row's slot line(s) as read through the scalar cache at the top of the trip -- a line is touched for
+  // the first time there, so the read misses the (incoherent) scalar cache and returns L2's current state; with the post
+  // D trips old it is normally complete and the poll below costs nothing.  Any sentinel left => the `glc` loop.
+  auto poll_line = [&](uint32_t gl, bool live, const ft_line* pre) -> double {     // gl: slot-line number = row of A (or mp + team)
+    double zs = 0.0;
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
+    for (int g = 0; g < NL / LG; ++g) {
+      ft_line line[LG];
+      bool have = false;
+      if (pre != nullptr && live && !dead) {
+        have = true;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) line[l][j] = 0u;
-    if (live && !dead) {
-      const double* lp = p.slots + (uint64_t)gl * TEAM;
-      unsigned cnt = 0u;
-      for (;;) {
-        if (NL == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
-        else asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                          : "=&s"(line[0]), "=&s"(line[NL - 1]) : "s"(lp) : "memory");
-        bool pending = false;
+        for (int l = 0; l < LG; ++l) {
+          line[l] = pre[g * LG + l];
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pending |= line[l][2 * j + 1] == FT_SENTINEL_HI;
-        if (!pending) break;
-        if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch (no p.err load in the
-          dead = true;                  // loop: a C-level load there would drain every prefetched row each trip)
-          if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-          for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (line[l][2 * j + 1] == FT_SENTINEL_HI) { line[l][2 * j] = 0u; line[l][2 * j + 1] = 0u; }
-          break;
+          for (int j = 0; j < 8; ++j) have &= line[l][2 * j + 1] != FT_SENTINEL_HI;
         }
-        if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
       }
-    }
-    double zs = __hiloint2double((int)line[0][1], (int)line[0][0]);
+      if (!have) {
 #pragma unroll
-    for (int j = 1; j < TEAM; ++j) zs += __hiloint2double((int)line[j / 8][2 * (j % 8) + 1], (int)line[j / 8][2 * (j % 8)]);   // member order: deterministic
+        for (int l = 0; l < LG; ++l)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) line[l][j] = 0u;
+      }
+      if (live && !dead && !have) {
+        const double* lp = p.slots + (uint64_t)gl * TEAM + g * (8 * LG);
+        unsigned cnt = 0u;
+        for (;;) {
+          if (LG == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
+          else asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                            : "=&s"(line[0]), "=&s"(line[LG - 1]) : "s"(lp) : "memory");
+          bool pending = false;
+#pragma unroll
+          for (int l = 0; l < LG; ++l)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pending |= line[l][2 * j + 1] == FT_SENTINEL_HI;
+          if (!pending) break;
+          if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch (no p.err load in the
+            dead = true;                  // loop: a C-level load there would drain every prefetched row each trip)
+            if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int l = 0; l < LG; ++l)
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (line[l][2 * j + 1] == FT_SENTINEL_HI) { line[l][2 * j] = 0u; line[l][2 * j + 1] = 0u; }
+            break;
+          }
+          if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (g == 0) zs = __hiloint2double((int)line[0][1], (int)line[0][0]);
+#pragma unroll
+      for (int j = (g == 0 ? 1 : 0); j < 8 * LG; ++j)             // member order: deterministic
+        zs += __hiloint2double((int)line[j / 8][2 * (j % 8) + 1], (int)line[j / 8][2 * (j % 8)]);
+    }
     return zs;
   };
   // lane 0 of ONE wave, after the barrier that follows the s_part writes: publish this member's partial of row r
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     block_reduce<1>(w1, s_scr, 1);
     if (tid == 0) store_partial(p.slots + (uint64_t)(p.mp + team) * TEAM + mem, w1[0]);
     if (wave == 0) {
-      const double t = poll_line(p.mp + team, true);
+      const double t = poll_line(p.mp + team, true, nullptr);
       if (lane == 0) s_bc[1] = t;
     }
     ft_lds_barrier();
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       if (wave == 0) {
         post_row(r, true);
         FT_T(3);
-        const double zs = poll_line(grow(r), true);
+        const double zs = poll_line(grow(r), true, nullptr);
         FT_T(4);
         if (lane == 0) {
           s_bc[0] = loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss);
@@ -356,6 +380,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           const double bi = bq[grow(min(r, r_last))];
           const double za = p.accel ? zq[grow(min(r, r_last))] : 0.0;
           load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
+          ft_line pre[NL];
+          if (EARLY) {
+            const auto* cp = (const __attribute__((address_space(4))) ft_line*)(uintptr_t)(p.slots + (uint64_t)grow(min(r, r_last)) * TEAM);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) pre[l] = cp[l];
+          }
           FT_T(0);
           const double d = dot_row(B[(j + D) % NB]);
           if (lane == 0) s_part[0] = d;
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           ft_lds_barrier();                                        // wave 1 posts row r+D from s_part[0..3]
           FT_T(2);
           FT_T(3);
-          const double zs = poll_line(grow(min(r, r_last)), live);
+          const double zs = poll_line(grow(min(r, r_last)), live, EARLY ? pre : nullptr);
           FT_T(4);
           if (lane == 0) {
             s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;

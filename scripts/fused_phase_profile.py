@@ -5,14 +5,14 @@ from fasta_python_amd import hip
 hip.load_library(os.path.join(os.path.dirname(hip.__file__), "libfasta_hip_prof.so"))
 import fasta_python_amd as fa
 from fasta_python_amd import synthetic
-for n, m in ((8192, 32768), (32768, 32768), (65536, 65536)):
+for n, m in ((32768, 16384), (65536, 16384), (131072, 16384)):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)
     ctx.set_loss_lsq(rng.randn(m)); ctx.set_prox(hip.PROX_SHRINK, 0.02)
     ctx.set_vector(hip.VEC_X0, rng.randn(n) * 0.01)
     ctx.init()
-    for v in (2, 10):
+    for v in (2,):
         ctx.set_tuning(hip.TUNE_FUSED_VARIANT, v)
         print(f"--- n={n} m={m} variant {v}", flush=True)
         ctx.step(0.2); ctx.step(0.2)

@@ -22,12 +22,12 @@ def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
 
 
 # variant bits: 2 = team members on one XCD (default), 0 = consecutive blocks, 8 = n=65536 as 8 members x 16 pieces with the
-# exchange in line (default there: 16 members x 8 pieces, exchange one trip ahead); n=131072 always runs 16 x 16 in line
+# exchange in line (default there: 16 members x 8 pieces, posts two rows ahead); n in (65536, 131072] runs 16 x 16 in line
 @pytest.mark.parametrize("variant", [2, 0, 10])
 @pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384), (130, 32768),
                                  (70, 65536), (40, 131072),
                                  # ragged n: the next shape up with the surplus lanes masked
-                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000)])
+                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000), (24, 100000)])
 def test_fused_step_equals_two_launch_step(m, n, variant):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
