@@ -1,3 +1,4 @@
+"""One-pass vs two-launch at 34 GB for different aspect ratios (GPU box)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

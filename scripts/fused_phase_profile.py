@@ -1,3 +1,5 @@
+"""Per-phase s_memtime ticks of the one-pass kernel's row loop (block 0, wave 0).  Needs the debug library:
+    make -C fasta_python_amd/csrc prof      (then run this on the GPU box)"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

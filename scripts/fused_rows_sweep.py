@@ -1,3 +1,4 @@
+"""One-pass kernel time vs number of rows at n = 65536 (GPU box)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
