@@ -611,7 +611,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
 }
 
 // n-side epilogue as its own launch (row-sharded runs, after the all-reduce of g1)
-static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src) {
+static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, const double* coef_src = nullptr) {
   AdjP p;
   memset(&p, 0, sizeof(p));
   p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n;
@@ -621,7 +621,7 @@ static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src) {
   FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
   p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
   t_begin(c, FH_K_AUX);
-  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src);
+  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src, coef_src);
   t_end(c, FH_K_AUX);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -801,7 +801,7 @@ struct FusedIO {
   int mode;     // 0 = with the n-side epilogue, 2 = g1 (+ loss) only
   // FISTA (zero-initialised = off): x1 = xp + c*(xp - xacc0), gradient at z + c*(z - zacc0), c = coef or 0 after a restart
   int accel = 0, restart = 0; double coef = 0.0;
-  const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr;
+  const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr; double* coef_out = nullptr;
 };
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
@@ -815,7 +815,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.b = c->b; p.z = io.z; p.tau = tau; p.loss = c->loss_kind; p.mode = io.mode;
   p.px = make_prox(c, tau);
   p.px.kind = io.kind;
-  p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1;
+  p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
   const unsigned grid = p.nteams * sh.team;
   const size_t slots_elems = ((size_t)c->mp + p.nteams) * sh.team;      // + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
@@ -1056,18 +1056,36 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
 
 // One-pass iteration WITH acceleration (fasta/__init__.py:220-248): the launch computes this step's restart dot before
 // its first row, applies `coef` unless (restart != 0 and the dot > 1e-30, :231) and reports the dot in FH_S_RDOT so that
-// the caller can update alpha the same way.  Dense operator, single GPU (a row-sharded run would need the dot all-reduced
-// before the first row).
+// the caller can update alpha the same way.  Dense operator.  Row-sharded runs work the same way: x, xprox and x_accel0
+// are replicated, so every rank computes the same dot and takes the same restart decision; the applied coefficient
+// travels to the separate n-side epilogue through a device scalar.
 extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, double* scalars) {
   FH_TRY(check_ready(c, true));
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "fh_step_accel: dense operator only");
-  if (c->comm) return fail(FH_E_STATE, "fh_step_accel: not available on a row-sharded operator (use fh_fwd + fh_adj)");
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], c->G[c->gc ^ 1], c->prox_kind, 0};
+  const bool sharded = c->comm != nullptr;
+  double* g1 = c->G[c->gc ^ 1];
+  double* coef_dev = c->dscal + FH_NSCALARS + 3;
+  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], g1, c->prox_kind, sharded ? 2 : 0};
   fio.accel = 1; fio.restart = restart ? 1 : 0; fio.coef = coef;
   fio.xacc0 = c->P[c->pc]; fio.zacc0 = c->Z[c->zc]; fio.x1 = c->X[c->ti];
+  fio.coef_out = sharded ? coef_dev : nullptr;
   FH_TRY(launch_fused_dense(c, tau, fio));
   c->last_accel = true;
+  if (sharded) {
+    t_begin(c, FH_K_COMM);
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ_ADJ, c->dscal + FH_S_FSQ_ADJ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    t_end(c, FH_K_COMM);
+    AdjIO io;
+    io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 1; io.coef = coef; io.mode = 0; io.tau = tau;
+    io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+    io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
+    FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ, coef_dev));
+  }
   return fetch_scalars(c, scalars);
 }
 

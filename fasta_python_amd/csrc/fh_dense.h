@@ -339,7 +339,9 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 
 // n-side epilogue as its own launch: used after the RCCL all-reduce when A is row-sharded
 // (g1 already holds the global sum).  grid = nchunks workgroups of 256 column pairs.
-__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p, uint32_t nchunks, const double* fsq_src) {
+__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t nchunks, const double* fsq_src, const double* coef_src) {
+  AdjP p = p_in;
+  if (coef_src) p.coef = *coef_src;      // FISTA coefficient decided on the device by the one-pass kernel (restart rule)
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x;

@@ -92,6 +92,7 @@ struct FusedP {
   int accel, restart;
   double coef;
   const double* xacc0; const double* zacc0; double* x1;
+  double* coef_out;      // optional: the coefficient actually applied (for the separate n-side epilogue of row-sharded runs)
   double* slots;         // [mp + nteams][TEAM] partial dot products (last nteams lines: restart dot), pre-filled with the sentinel
   double* gpart;         // [nteams][ld]
   double* g1;
@@ -202,34 +203,19 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   typedef unsigned ft_line __attribute__((ext_vector_type(16)));
   constexpr int NL = TEAM / 8;                     // 64-byte slot lines per row
   constexpr int LG = NL < 2 ? NL : 2;              // lines per poll: at most two (32 SGPRs); 32 members poll twice
-  // speculative read of the slot line(s) at the top of the trip: not for 8 members x 8 pieces, whose loop has no register left
-  // (measured: 32768^2 1.24 -> 1.30 ms with it, 8192 x 32768 0.71 -> 0.64 ms, 65536^2 5.05 -> 4.98 ms)
-  constexpr bool EARLY = PIPE != 0 && NL <= 2 && (PPT < 8 || TEAM >= 16);
-  // `pre` (EARLY): the row's slot line(s) as read through the scalar cache at the top of the trip -- a line is touched for
-  // the first time there, so the read misses the (incoherent) scalar cache and returns L2's current state; with the post
-  // D trips old it is normally complete and the poll below costs nothing.  Any sentinel left => the `glc` loop.
-  auto poll_line = [&](uint32_t gl, bool live, const ft_line* pre) -> double {     // gl: slot-line number = row of A (or mp + team)
+  // (A speculative read of the slot line at the top of the trip through the scalar cache -- no `glc`, compiler-visible --
+  // was tried: it returned stale bytes from before the launch's sentinel fill now and then, i.e. WRONG RESULTS; every
+  // slot read therefore stays a `glc` load inside the bounded loop below.  profiles/r01d_fused_tuning.txt, item 6.)
+  auto poll_line = [&](uint32_t gl, bool live) -> double {     // gl: slot-line number = row of A (or mp + team)
     double zs = 0.0;
 #pragma unroll
     for (int g = 0; g < NL / LG; ++g) {
       ft_line line[LG];
-      bool have = false;
-      if (pre != nullptr && live && !dead) {
-        have = true;
 #pragma unroll
-        for (int l = 0; l < LG; ++l) {
-          line[l] = pre[g * LG + l];
+      for (int l = 0; l < LG; ++l)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) have &= line[l][2 * j + 1] != FT_SENTINEL_HI;
-        }
-      }
-      if (!have) {
-#pragma unroll
-        for (int l = 0; l < LG; ++l)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) line[l][j] = 0u;
-      }
-      if (live && !dead && !have) {
+        for (int j = 0; j < 16; ++j) line[l][j] = 0u;
+      if (live && !dead) {
         const double* lp = p.slots + (uint64_t)gl * TEAM + g * (8 * LG);
         unsigned cnt = 0u;
         for (;;) {
@@ -294,7 +280,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     block_reduce<1>(w1, s_scr, 1);
     if (tid == 0) store_partial(p.slots + (uint64_t)(p.mp + team) * TEAM + mem, w1[0]);
     if (wave == 0) {
-      const double t = poll_line(p.mp + team, true, nullptr);
+      const double t = poll_line(p.mp + team, true);
       if (lane == 0) s_bc[1] = t;
     }
     ft_lds_barrier();
@@ -322,7 +308,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       if (wave == 0) {
         post_row(r, true);
         FT_T(3);
-        const double zs = poll_line(grow(r), true, nullptr);
+        const double zs = poll_line(grow(r), true);
         FT_T(4);
         if (lane == 0) {
           s_bc[0] = loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss);
@@ -380,12 +366,6 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           const double bi = bq[grow(min(r, r_last))];
           const double za = p.accel ? zq[grow(min(r, r_last))] : 0.0;
           load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
-          ft_line pre[NL];
-          if (EARLY) {
-            const auto* cp = (const __attribute__((address_space(4))) ft_line*)(uintptr_t)(p.slots + (uint64_t)grow(min(r, r_last)) * TEAM);
-#pragma unroll
-            for (int l = 0; l < NL; ++l) pre[l] = cp[l];
-          }
           FT_T(0);
           const double d = dot_row(B[(j + D) % NB]);
           if (lane == 0) s_part[0] = d;
@@ -393,7 +373,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           ft_lds_barrier();                                        // wave 1 posts row r+D from s_part[0..3]
           FT_T(2);
           FT_T(3);
-          const double zs = poll_line(grow(min(r, r_last)), live, EARLY ? pre : nullptr);
+          const double zs = poll_line(grow(min(r, r_last)), live);
           FT_T(4);
           if (lane == 0) {
             s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
@@ -535,6 +515,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       p.out[S_DXDG] = bq[0]; p.out[S_DG2] = bq[1]; p.out[S_XH2_ADJ] = bq[2]; p.out[S_GSUM_ADJ] = bq[3];
       p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = p.accel ? a[7] : a[0];
       p.out[S_ALPHA] = level;
+      if (p.coef_out) *p.coef_out = coef;
       p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
     }
   }

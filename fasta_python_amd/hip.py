@@ -231,7 +231,7 @@ class HipContext:
 
     def step_accel(self, tau, coef, restart):
         """One-pass K-fwd + K-adj with FISTA extrapolation: `coef` applies unless `restart` and this step's restart
-        dot (returned in S_RDOT) exceeds 1e-30.  Dense operator, single GPU."""
+        dot (returned in S_RDOT) exceeds 1e-30.  Dense operator."""
         self._call("fh_step_accel", float(tau), float(coef), 1 if restart else 0, self._scal_p)
         if self._scal[15] != 0.0:
             raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")

@@ -96,7 +96,7 @@ class FBSolver:
                  record_iterates=False, func=None, *, fused="auto"):
         """Reference options (fasta/__init__.py:42-53) plus one build-only, keyword-only switch:
         fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step` / `step_accel`, csrc/fh_fused.h)
-        when the operator shape supports it (with acceleration: dense operator on one GPU).  It is speculative: the
+        when the operator shape supports it (with acceleration: dense operator only).  It is speculative: the
         launch assumes the step is accepted; when the backtracking test fails the iteration falls back to
         K-fwd/K-adj (same results)."""
         self.A, self.loss, self.prox = A, loss, prox
@@ -164,8 +164,8 @@ class FBSolver:
         kind = c.fused_supported() if self.fused_opt is not False else 0
         if kind == 3 and self.fused_opt is not True:        # available but slower than two launches at this size
             kind = 0
-        if self.accelerate and (kind == 2 or getattr(c, "sharded", False)):
-            kind = 0        # FISTA in one pass: dense operator on one GPU only (the restart dot precedes the first row)
+        if self.accelerate and kind == 2:
+            kind = 0        # FISTA in one pass: dense operator only (the stencil sweep has no place for the restart dot)
         self.use_fused = kind != 0
         # Where the one-pass kernel costs no more than K-fwd alone -- the stencil, and the dense operator from n = 16384
         # (kind 1: 65536^2 5.0 ms vs K-fwd 4.9 ms) -- it also serves the backtracking retries.  A dense operator below

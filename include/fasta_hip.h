@@ -145,7 +145,7 @@ int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
  * 3 = dense, available but slower than the two launches (n < 16384); 2 = stencil operator (one sweep replaces both).  */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
-/* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, single GPU): as fh_step, plus
+/* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, also row-sharded): as fh_step, plus
  * x1 = xprox + c*(xprox - x_accel0) and the gradient taken at z1 + c*(z1 - z_accel0) with c = coef, or 0 when restart != 0
  * and this step's restart dot <x0 - xprox, xprox - x_accel0> (:231) exceeds 1e-30; the dot is returned in FH_S_RDOT and
  * f at the extrapolated point in FH_S_FSQ_ADJ, so the caller updates alpha exactly as after fh_fwd + fh_adj.            */

@@ -197,14 +197,18 @@ def test_full_solve_with_fused_steps_matches_oracle(kind):
     np.testing.assert_allclose(got.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
 
 
-def test_fused_step_on_the_row_sharded_path_with_one_rank():
-    """fh_step with a communicator: local one-pass kernel -> RCCL all-reduce of g1 and ||r||^2 -> n-side epilogue."""
+@pytest.mark.parametrize("accelerate", [False, True])
+def test_fused_step_on_the_row_sharded_path_with_one_rank(accelerate):
+    """fh_step / fh_step_accel with a communicator: local one-pass kernel -> RCCL all-reduce of g1 and the loss sums ->
+    n-side epilogue (with the FISTA coefficient the kernel decided on)."""
     rng = np.random.RandomState(11)
     m, n = 300, 4096
     A = rng.randn(m, n) / 30
     b = rng.randn(m)
     ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
     opts = dict(tolerance=1e-6, max_iters=30, evaluate_objective=True)
+    if accelerate:
+        opts.update(adaptive=False, accelerate=True, max_iters=60)
     op = fa.DenseMatrixMap(A)
     try:
         np.random.seed(1)
