@@ -43,5 +43,18 @@ int main() {
     }
     printf("buffer rewritten by %-18s: %u stale scalar reads in 50 rounds x 1024 workgroups x %u lines\n", how[mode], total_bad, n / 16);
   }
+  // the same without any host synchronisation between the launches (one stream, back-to-back dispatches)
+  for (int mode = 0; mode < 2; ++mode) {
+    CHECK(hipMemsetAsync(bad, 0, 4, 0));
+    for (unsigned round = 1; round <= 200; ++round) {
+      const unsigned v = 5000 + mode * 1000 + round;
+      if (mode == 0) k_fill<<<64, 256>>>(buf, n, v);
+      else CHECK(hipMemsetD32Async((hipDeviceptr_t)buf, (int)v, n, 0));
+      k_sread<<<1024, 64>>>(buf, n, v, bad);
+    }
+    unsigned b = 0;
+    CHECK(hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost));
+    printf("back-to-back, rewritten by %-18s: %u stale scalar reads in 200 rounds\n", mode == 0 ? "fill kernel" : "hipMemsetD32Async", b);
+  }
   return 0;
 }

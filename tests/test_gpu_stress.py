@@ -78,3 +78,44 @@ def test_tv_one_pass_kernel_is_bitwise_repeatable():
         assert np.array_equal(c.get_vector(hip.VEC_XPROX, 2 * H_ * W_), xp0)
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("accel", [False, True])
+@pytest.mark.parametrize("m,n,reps", [(70, 65536, 25), (300, 4096, 40), (90, 20000, 30), (4000, 32768, 12), (3000, 65536, 10)])
+def test_one_pass_kernel_never_consumes_a_previous_launch_s_partials(m, n, reps, accel):
+    """Consecutive launches reuse the same slot lines.  Alternate between two different iterates and check every launch
+    against its own two-launch reference: a slot value left over from the previous launch (a read that bypasses the
+    sentinel protocol, e.g. through a non-coherent cache) would be a plausible number for the WRONG x."""
+    rng = np.random.RandomState(m ^ n)
+    if m * n <= 2 ** 23:       # small cases from a host matrix (fh_set_matrix), the large ones generated on the device
+        op = fa.DenseMatrixMap(rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n)))
+    else:
+        op = fa.DenseMatrixMap.synthetic(m, n, 11, synthetic.lasso_scale(m, n))
+    c = op.ctx
+    b = rng.randn(m)
+    xs = [rng.randn(n) * 0.05, rng.randn(n) * 0.2]
+    tau = 0.3
+
+    def state(x):
+        c.set_loss_lsq(b); c.set_prox(hip.PROX_SHRINK, 0.02); c.set_vector(hip.VEC_X0, x); c.init()
+        if accel:      # one committed iteration so that x_accel0 / z_accel0 are not x0 / z0
+            c.fwd(tau); c.adj(tau, True, 0.0); c.commit()
+
+    try:
+        refs = []
+        for x in xs:
+            state(x)
+            s = c.fwd(tau)
+            a = c.adj(tau, accel, 0.3 if accel else 0.0)
+            refs.append((s[hip.S_FSQ], a[hip.S_DXDG], c.get_vector(hip.VEC_Z, m), c.get_vector(hip.VEC_G1, n)))
+        for k in range(reps):
+            which = k % 2
+            state(xs[which])
+            f = c.step_accel(tau, 0.3, False) if accel else c.step(tau)
+            fsq, dxdg, z, g = refs[which]
+            np.testing.assert_allclose(f[hip.S_FSQ], fsq, rtol=1e-12, err_msg=f"launch {k}")
+            np.testing.assert_allclose(f[hip.S_DXDG], dxdg, rtol=1e-9, err_msg=f"launch {k}")
+            np.testing.assert_allclose(c.get_vector(hip.VEC_Z, m), z, rtol=1e-12, atol=1e-14, err_msg=f"launch {k}")
+            np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), g, rtol=1e-9, atol=1e-13, err_msg=f"launch {k}")
+    finally:
+        op.close()
