@@ -983,6 +983,24 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
   return fetch_scalars(c, scalars);
 }
 
+// K-fwd and K-adj of the same tau enqueued back to back, ONE synchronisation (no acceleration): for callers that
+// speculate on the step being accepted when the launches are short and the host round trip is what costs
+// (fasta/__init__.py:181-188 and :248-260 in one call; a rejected step has wasted the K-adj launch).
+extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
+  FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
+  FH_TRY(reduce_fsq_over_ranks(c));
+  AdjIO io;
+  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = 0; io.coef = 0.0;
+  io.mode = 0; io.tau = tau;
+  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
+  c->last_accel = false;
+  FH_TRY(op_adj(c, io));
+  return fetch_scalars(c, scalars);
+}
+
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
   // 0 = unsupported; 1 = dense one-pass kernel, recommended (speculative: a rejected step wastes the A^T half);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_fwd_adj": (_i32, [_ctx, _dbl, _pd]),
     "fh_step": (_i32, [_ctx, _dbl, _pd]),
     "fh_step_accel": (_i32, [_ctx, _dbl, _dbl, _i32, _pd]),
     "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
@@ -213,6 +214,11 @@ class HipContext:
 
     def adj(self, tau, accel=False, coef=0.0):
         self._call("fh_adj", float(tau), 1 if accel else 0, float(coef), self._scal_p)
+        return self._scal.copy()
+
+    def fwd_adj(self, tau):
+        """K-fwd + K-adj (no acceleration) under one synchronisation: both halves of the scalar block."""
+        self._call("fh_fwd_adj", float(tau), self._scal_p)
         return self._scal.copy()
 
     def fused_supported(self):

@@ -26,6 +26,7 @@ from .proximal import NoProx, ProxTag
 
 __all__ = ["fasta", "Convergence", "FBSolver", "EPSILON"]
 
+PAIR_MAX_ELEMENTS = 1 << 26     # dense operators up to 64 Mi elements (<= ~0.1 ms per launch) take K-fwd + K-adj under one sync
 EPSILON = 1E-12      # fasta/__init__.py:32
 
 
@@ -162,20 +163,32 @@ class FBSolver:
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
         kind = c.fused_supported() if self.fused_opt is not False else 0
-        if kind == 3 and self.fused_opt is not True:        # available but slower than two launches at this size
-            kind = 0
         if self.accelerate and kind == 2:
             kind = 0        # FISTA in one pass: dense operator only (the stencil sweep has no place for the restart dot)
-        self.use_fused = kind != 0
-        # Where the one-pass kernel costs no more than K-fwd alone -- the stencil, and the dense operator from n = 16384
-        # (kind 1: 65536^2 5.0 ms vs K-fwd 4.9 ms) -- it also serves the backtracking retries.  A dense operator below
-        # that (kind 3, only with fused=True) uses it speculatively and backs off after a backtrack: there a rejected
-        # step wastes the A^T half.
-        self.fused_always = kind in (1, 2)
+        # How the two halves of an iteration reach the device:
+        #   "always"      one-pass kernel for every launch of the loop, backtracking retries included: where it costs no more
+        #                 than K-fwd alone -- the stencil, and the dense operator from n = 16384 (kind 1: 65536^2 5.0 vs 4.9 ms)
+        #   "speculative" one-pass kernel on a dense operator below that size (kind 3, only with fused=True): a rejected step
+        #                 wastes the A^T half, so back off for a few iterations after a backtrack
+        #   "pair"        K-fwd and K-adj enqueued back to back under one synchronisation (fused="auto", short launches, no
+        #                 acceleration): the host round trip is what costs there; speculative in the same way
+        #   None          fh_fwd, decide, fh_adj
+        self.mode = None
+        if kind in (1, 2):
+            self.mode = "always"
+        elif kind == 3 and self.fused_opt is True:
+            self.mode = "speculative"
+        elif (self.fused_opt == "auto" and kind in (0, 3) and not self.accelerate and hasattr(c, "fwd_adj")
+              and getattr(self.A, "shape", None) is not None and len(self.A.shape) == 2
+              and self.A.shape[0] * self.A.shape[1] <= PAIR_MAX_ELEMENTS):
+            self.mode = "pair"
+        self.use_fused = self.mode in ("always", "speculative")
+        self.fused_always = self.mode == "always"
         if self.fused_opt is True and not self.use_fused:
             raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator without acceleration")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
+        self.pair_steps = 0
         self.alpha1 = 1.0                                               # :157
         self.max_residual = -np.inf                                     # :165-167
         self.best_quality = np.inf
@@ -187,6 +200,10 @@ class FBSolver:
     def _forward(self, tau, one_pass):
         """(fwd scalars, adj scalars or None): the one-pass kernel when enabled and asked for, else K-fwd alone."""
         c = self.ctx
+        if self.mode == "pair" and one_pass:
+            self.pair_steps += 1
+            s = c.fwd_adj(tau)
+            return s, s
         if self.use_fused and one_pass:
             try:
                 if self.accelerate:     # the launch decides the restart itself (:231); step() mirrors it afterwards

@@ -137,6 +137,9 @@ int fh_fwd(fh_ctx* ctx, double tau, double* scalars);
  * x1 = xprox + coef*(xprox - x_accel0) (coef = 0 and accel = 0 without acceleration, :242-243);
  * g1 = A^H (z1' - b) (:248); reductions FH_S_DXDG..FH_S_GMAX_ADJ (:254-260, 274, 285).          */
 int fh_adj(fh_ctx* ctx, double tau, int accel, double coef, double* scalars);
+/* fh_fwd followed by fh_adj (no acceleration) under ONE synchronisation: the complete FH_S_* block comes back in one round
+ * trip.  For short launches, where the host round trip dominates; the caller speculates on the step being accepted.      */
+int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
 /* ONE-PASS iteration (dense operator, no acceleration): K-fwd and K-adj of the same tau from a SINGLE read of A
  * (teams of 8 or 16 co-resident workgroups exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
  * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it

@@ -18,7 +18,7 @@ class FakeContext:
         self.fwd_op, self.adj_op = fwd, adj
         self.n_shape, self.m_shape = tuple(n_shape), tuple(m_shape)
         self.fused_kind = fused_kind
-        self.calls = {"fwd": 0, "adj": 0, "step": 0}
+        self.calls = {"fwd": 0, "adj": 0, "step": 0, "pair": 0}
         self.vec = {}
         self.loss = "lsq"
         self.prox_kind, self.mu, self.lo, self.hi = hip.PROX_IDENTITY, 0.0, 0.0, 0.0
@@ -145,6 +145,14 @@ class FakeContext:
         self.calls["adj"] -= 1
         return s
 
+    def fwd_adj(self, tau):
+        self.calls["pair"] += 1
+        self.fwd(tau)
+        self.calls["fwd"] -= 1
+        s = self.adj(tau)
+        self.calls["adj"] -= 1
+        return s
+
     def step_accel(self, tau, coef, restart):
         self.calls["step"] += 1
         s = self.fwd(tau)
@@ -170,6 +178,7 @@ class FakeDenseMap(_DeviceMap):
     def __init__(self, A, fused_kind=0):
         A = np.asarray(A, dtype=float)
         self.matrix = A
+        self.shape = A.shape
         self.ctx = FakeContext(lambda x: A @ x, lambda y: A.T @ y, (A.shape[1],), (A.shape[0],), fused_kind)
         LinearMap.__init__(self, self.ctx.fwd_op, self.ctx.adj_op, (A.shape[1],), (A.shape[0],))
 

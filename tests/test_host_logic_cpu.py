@@ -65,6 +65,12 @@ def test_driver_reproduces_reference_run(name, fused):
             assert ctx.calls["fwd"] == 0 and ctx.calls["adj"] == 0 # ... for every launch of the loop
     else:
         assert ctx.calls["step"] == 0
+    if not fused and meta["kind"] != "tv" and not accelerated:
+        assert ctx.calls["pair"] > 0                               # short launches: K-fwd + K-adj under one synchronisation
+        if c.backtracks:
+            assert ctx.calls["fwd"] > 0 and ctx.calls["adj"] > 0   # retries and the cool-down iterations go the plain way
+    else:
+        assert ctx.calls["pair"] == 0
 
 
 def test_speculation_backs_off_after_a_backtrack():
