@@ -208,43 +208,39 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // slot read therefore stays a `glc` load inside the bounded loop below.  profiles/r01d_fused_tuning.txt, item 6.)
   auto poll_line = [&](uint32_t gl, bool live) -> double {     // gl: slot-line number = row of A (or mp + team)
     double zs = 0.0;
+    if (live && !dead) {           // (the slot values live in SGPRs inside this branch only: no copies at the joins)
 #pragma unroll
-    for (int g = 0; g < NL / LG; ++g) {
-      ft_line line[LG];
-#pragma unroll
-      for (int l = 0; l < LG; ++l)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) line[l][j] = 0u;
-      if (live && !dead) {
+      for (int g = 0; g < NL / LG; ++g) {
+        ft_line line[LG];
         const double* lp = p.slots + (uint64_t)gl * TEAM + g * (8 * LG);
         unsigned cnt = 0u;
         for (;;) {
           if (LG == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
           else asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
                             : "=&s"(line[0]), "=&s"(line[LG - 1]) : "s"(lp) : "memory");
-          bool pending = false;
+          // (readfirstlane: inline-asm results count as divergent, which would put these compares on the vector ALU)
+          unsigned pending = 0u;
 #pragma unroll
           for (int l = 0; l < LG; ++l)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pending |= line[l][2 * j + 1] == FT_SENTINEL_HI;
-          if (!pending) break;
-          if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch (no p.err load in the
-            dead = true;                  // loop: a C-level load there would drain every prefetched row each trip)
+            for (int j = 0; j < 8; ++j)
+              pending |= (unsigned)__builtin_amdgcn_readfirstlane((int)line[l][2 * j + 1]) == FT_SENTINEL_HI ? 1u : 0u;
+          if (pending == 0u) break;
+          if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch: the launch is reported as
+            dead = true;                  // timed out (p.err) and its results are discarded, so the values no longer matter
             if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int l = 0; l < LG; ++l)
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (line[l][2 * j + 1] == FT_SENTINEL_HI) { line[l][2 * j] = 0u; line[l][2 * j + 1] = 0u; }
-            break;
+            break;                        // (no p.err LOAD anywhere in the loop: it would drain every prefetched row each trip)
           }
           if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
         }
-      }
-      if (g == 0) zs = __hiloint2double((int)line[0][1], (int)line[0][0]);
 #pragma unroll
-      for (int j = (g == 0 ? 1 : 0); j < 8 * LG; ++j)             // member order: deterministic
-        zs += __hiloint2double((int)line[j / 8][2 * (j % 8) + 1], (int)line[j / 8][2 * (j % 8)]);
+        for (int j = 0; j < 8 * LG; ++j) {                          // member order: deterministic
+          const double q = __hiloint2double(__builtin_amdgcn_readfirstlane((int)line[j / 8][2 * (j % 8) + 1]),
+                                            __builtin_amdgcn_readfirstlane((int)line[j / 8][2 * (j % 8)]));
+          zs = (g == 0 && j == 0) ? q : zs + q;
+        }
+      }
+      if (dead) zs = 0.0;
     }
     return zs;
   };
