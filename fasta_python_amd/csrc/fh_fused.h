@@ -31,10 +31,12 @@
 //   partials for their share of the columns in team order and run the n-side epilogue (same arithmetic as
 //   K-adj's finaliser), last arriver sums the scalars.  No float atomics: bitwise repeatable.
 //
-// Used speculatively by the host driver (solver.py): the launch assumes the step will be accepted; if the
-// backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj as usual (identical
-// results either way).  With acceleration (p.accel, fh_step_accel) the FISTA coefficient depends on this launch's own
-// restart dot: every team exchanges it through one extra slot line before its first row.  Requires n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
+// Host driver (solver.py): from n = 16384 the launch costs what K-fwd alone costs, so it serves every launch of the loop,
+// backtracking retries included; below that it is used speculatively (the launch assumes the step will be accepted; if
+// the backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj: identical results either way).
+// With acceleration (p.accel, fh_step_accel) the FISTA coefficient depends on this launch's own restart dot: every team
+// exchanges it through one extra slot line before its first row.
+// Requires n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
 // address, carry x = 0 and are masked out of every store (fasta_hip.hip:fused_shape picks the next shape up).
 #pragma once
 #include "fh_dense.h"
@@ -99,13 +101,9 @@ struct FusedP {
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
   unsigned* err;         // set to 1 on a spin timeout
-  int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
+  int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep between polls, 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
   double* out;
 };
-
-__device__ __forceinline__ bool ft_is_sentinel(double v) {
-  return (unsigned)(__double_as_longlong(v) >> 32) == FT_SENTINEL_HI && (unsigned)__double_as_longlong(v) == FT_SENTINEL_HI;
-}
 
 template <int PPT, int NT, int PIPE, int TEAM>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
