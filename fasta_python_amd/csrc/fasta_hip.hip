@@ -764,11 +764,16 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 
 // ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
 // Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row; lanes past the row's last
-// piece are masked (clamped loads, zero x), so any n up to 131072 fits the next shape up:
-//   n <= 32768 : 8 members x PPT = ceil(n/4096) pieces (rounded up to 1, 2, 4 below 16384), posts one row ahead
-//   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead; FH_TUNE_FUSED_VARIANT bit 8 and n = 65536:
-//                8 members x 16 pieces with the exchange in line (three row buffers are all its registers hold)
-//   n <= 131072: 16 members x 16 pieces, exchange in line
+// piece are masked (clamped loads, zero x), so any n up to 131072 fits the next shape up.  A member's piece of a row is
+// kept at 5..8 pieces per lane (20-32 KiB per workgroup per row) by choosing the team size -- fewer members means more
+// teams, i.e. fewer rows (trips of ~0.7-1.2 us) per team:
+//   n <= 4096  : 1 member  (a workgroup owns whole rows: no exchange), PPT = ceil(n/512) rounded up to 1, 2, 4, 5..8
+//   n <= 8192  : 2 members x PPT = ceil(n/1024) in 5..8, posts one row ahead
+//   n <= 16384 : 4 members x PPT = ceil(n/2048) in 5..8, posts one row ahead
+//   n <= 32768 : 8 members x PPT = ceil(n/4096) in 5..8, posts one row ahead
+//   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead
+//   n <= 131072: 16 members x 16 pieces, exchange in line (three row buffers are all its registers hold)
+// FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536.
 // Teams of 32 (n <= 131072 with posts two or three rows ahead, n <= 262144 in line) were built and measured: a trip costs
 // 1.65 us with 32 members, so they only tie the shapes above / the two-launch path (profiles/r01d_fused_tuning.txt).
 struct FusedShape { int ppt, team, pipe; };
@@ -778,7 +783,15 @@ static FusedShape fused_shape(fh_ctx* c) {
   const uint64_t pieces = round_up(c->n, 16) / 2;    // 16-byte pieces per row that hold data (the row stride c->ld may be padded)
   if (pieces > c->ld / 2) return none;
   FusedShape sh = none;
-  if (pieces <= (uint64_t)8 * FH_WG * 8) {
+  if (pieces <= (uint64_t)1 * FH_WG * 8 && !(c->fused_variant & 8)) {
+    int ppt = (int)((pieces + FH_WG - 1) / FH_WG);                       // n <= 4096: a workgroup owns whole rows, 256 "teams" of one
+    if (ppt == 3) ppt = 4;
+    sh = {ppt, 1, 1};
+  } else if (pieces > (uint64_t)1 * FH_WG * 8 && pieces <= (uint64_t)2 * FH_WG * 8 && !(c->fused_variant & 8)) {
+    sh = {(int)((pieces + 2 * FH_WG - 1) / (2 * FH_WG)), 2, 1};        // n in (4096, 8192]: 2 members x 5..8 pieces, 128 teams
+  } else if (pieces > (uint64_t)2 * FH_WG * 8 && pieces <= (uint64_t)4 * FH_WG * 8 && !(c->fused_variant & 8)) {
+    sh = {(int)((pieces + 4 * FH_WG - 1) / (4 * FH_WG)), 4, 1};        // n in (8192, 16384]: 4 members x 5..8 pieces, 64 teams
+  } else if (pieces <= (uint64_t)8 * FH_WG * 8) {
     int ppt = (int)((pieces + 8 * FH_WG - 1) / (8 * FH_WG));
     if (ppt == 3) ppt = 4;
     sh = {ppt, 8, 1};
@@ -793,6 +806,8 @@ static FusedShape fused_shape(fh_ctx* c) {
   return sh;
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
+// the one-pass launch beats K-fwd + K-adj once its fixed cost is amortised: wide rows, or at least 32 Mi elements
+static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 25); }
 
 // the prox kind travels in p.px.kind (run-time switch in the kernel's n-side prologue); FH_PROX_* == PX_* numerically
 template <int PPT, int PIPE, int TEAM>
@@ -825,7 +840,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.px.kind = io.kind;
   p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
   const unsigned grid = p.nteams * sh.team;
-  const size_t slots_elems = ((size_t)c->mp + p.nteams) * sh.team;      // + one line per team for the restart dot
+  const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);   // whole 64-byte lines; + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
   FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
@@ -835,7 +850,31 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   t_begin(c, FH_K_FUSED);
   HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-  if (sh.team == 8 && sh.pipe) {
+  if (sh.team == 1) {
+    switch (sh.ppt) {
+      case 1: launch_fused_p<1, 1, 1>(c, p, grid, io.kind); break;
+      case 2: launch_fused_p<2, 1, 1>(c, p, grid, io.kind); break;
+      case 4: launch_fused_p<4, 1, 1>(c, p, grid, io.kind); break;
+      case 5: launch_fused_p<5, 1, 1>(c, p, grid, io.kind); break;
+      case 6: launch_fused_p<6, 1, 1>(c, p, grid, io.kind); break;
+      case 7: launch_fused_p<7, 1, 1>(c, p, grid, io.kind); break;
+      default: launch_fused_p<8, 1, 1>(c, p, grid, io.kind); break;
+    }
+  } else if (sh.team == 2) {
+    switch (sh.ppt) {
+      case 5: launch_fused_p<5, 1, 2>(c, p, grid, io.kind); break;
+      case 6: launch_fused_p<6, 1, 2>(c, p, grid, io.kind); break;
+      case 7: launch_fused_p<7, 1, 2>(c, p, grid, io.kind); break;
+      default: launch_fused_p<8, 1, 2>(c, p, grid, io.kind); break;
+    }
+  } else if (sh.team == 4) {
+    switch (sh.ppt) {
+      case 5: launch_fused_p<5, 1, 4>(c, p, grid, io.kind); break;
+      case 6: launch_fused_p<6, 1, 4>(c, p, grid, io.kind); break;
+      case 7: launch_fused_p<7, 1, 4>(c, p, grid, io.kind); break;
+      default: launch_fused_p<8, 1, 4>(c, p, grid, io.kind); break;
+    }
+  } else if (sh.team == 8 && sh.pipe) {
     switch (sh.ppt) {
       case 1: launch_fused_p<1, 1, 8>(c, p, grid, io.kind); break;
       case 2: launch_fused_p<2, 1, 8>(c, p, grid, io.kind); break;
@@ -862,9 +901,9 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   return 0;
 }
 
-// z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, n >= 16384):
+// z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, fused_pays()):
 // identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
-static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && c->n >= 16384; }
+static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && fused_pays(c); }
 // returns 0 and sets *ok = false when the launch reported a spin timeout (caller falls back to two launches)
 static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bool* ok) {
   const FusedIO fio = {x, x, c->xhat, c->P[c->pc ^ 1], z, g, FH_PROX_IDENTITY, 2};
@@ -1011,13 +1050,13 @@ extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
 
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
-  // 0 = unsupported; 1 = dense one-pass kernel, recommended (speculative: a rejected step wastes the A^T half);
+  // 0 = unsupported; 1 = dense one-pass kernel, recommended;
   // 2 = stencil one-pass kernel (costs no more than K-fwd alone: it simply replaces both launches);
-  // 3 = dense one-pass kernel available but NOT recommended: a trip of the row loop cannot go below ~0.66 us (barriers,
-  //     cross-lane sums, one scalar poll), which only pays once a team member's piece of a row is >= 16 KiB, i.e.
-  //     n >= 16384 (profiles/r01d_fused_tuning.txt: 16384^2 0.39 vs 0.66 ms, 8192^2 0.198 vs 0.180 ms)
+  // 3 = dense one-pass kernel available but NOT recommended: its launch has ~35-50 us of fixed cost (slot fill, n-side
+  //     prologue, grid barrier, epilogue), which two short launches under one sync beat on a small matrix
+  //     (profiles/r01d_fused_tuning.txt item 8: 4096^2 81 vs 77 us, 16384 x 4096 140 vs 204 us, 512 x 16384 66 vs 72 us)
   const int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
-  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (c->n >= 16384 ? 1 : 3) : 0);
+  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
   return 0;
 }
 

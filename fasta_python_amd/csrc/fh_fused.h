@@ -2,8 +2,8 @@
 // single read of A (the two-launch path reads A twice: 2*m*n*8 bytes per iteration; this reads m*n*8).
 //
 // Why it is possible: g1 = sum_i a_i * r_i with r_i = grad f(a_i . xprox) -- row i is needed twice, first
-// whole (the dot product), then again for the rank-1 update.  A row (up to 1 MiB) does not fit one CU, so a TEAM
-// of 8 or 16 co-resident workgroups splits the columns: each member keeps its piece of the row (PPT 16-byte
+// whole (the dot product), then again for the rank-1 update.  A row (up to 1 MiB) does not fit one CU beyond n = 4096, so
+// a TEAM of 2, 4, 8 or 16 co-resident workgroups splits the columns (one workgroup owns whole rows up to n = 4096): each member keeps its piece of the row (PPT 16-byte
 // pieces per lane) IN REGISTERS, publishes its partial dot product as one write-through (`sc1`) 8-byte store into
 // the row's slot line(s), reads the whole line back with scalar loads until no slot holds the sentinel (bounded),
 // sums the partials in member order, and applies r_i * (its row pieces) to its register-resident slice of g1.
@@ -41,7 +41,7 @@
 #pragma once
 #include "fh_dense.h"
 
-#define FT_TEAM_MAX 16                              // members per team: 8 or 16 (template parameter TEAM; 32 works, see fused_shape)
+#define FT_TEAM_MAX 16                              // members per team: 1, 2, 4, 8 or 16 (template parameter TEAM; 32 works, see fused_shape)
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock (grid barrier)
 #define FT_SPIN_POLLS 1000000u                      // slot-poll budget: ~0.3-0.5 us per poll (s_load glc + s_sleep) => ~0.4 s
@@ -95,7 +95,7 @@ struct FusedP {
   double coef;
   const double* xacc0; const double* zacc0; double* x1;
   double* coef_out;      // optional: the coefficient actually applied (for the separate n-side epilogue of row-sharded runs)
-  double* slots;         // [mp + nteams][TEAM] partial dot products (last nteams lines: restart dot), pre-filled with the sentinel
+  double* slots;         // [mp + nteams][max(TEAM, 8)] partial dot products (last nteams lines: restart dot), pre-filled with the sentinel
   double* gpart;         // [nteams][ld]
   double* g1;
   double* red;           // [grid][16] reduction partials
@@ -108,6 +108,7 @@ struct FusedP {
 template <int PPT, int NT, int PIPE, int TEAM>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   __shared__ __attribute__((aligned(16))) double s_part[4];
+  __shared__ __attribute__((aligned(16))) double s_part2[2][4];  // TEAM == 1: wave partials, double-buffered by trip parity
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // XCDs, sc1 store -> sc1 vector load 0.6-0.9 us.  The loop itself is plain C around the asm load: it contains no
   // compiler-visible vector memory operation, so hipcc's vmcnt bookkeeping for the row buffers stays exact.
   typedef unsigned ft_line __attribute__((ext_vector_type(16)));
-  constexpr int NL = TEAM / 8;                     // 64-byte slot lines per row
+  constexpr int SL = TEAM < 8 ? 8 : TEAM;          // doubles per row in the slot array: whole 64-byte lines (teams of 2 / 4 use the first slots)
+  constexpr int NL = SL / 8;                       // 64-byte slot lines per row
   constexpr int LG = NL < 2 ? NL : 2;              // lines per poll: at most two (32 SGPRs); 32 members poll twice
+  constexpr int MG = TEAM < 8 ? TEAM : 8 * LG;     // members per poll
   // (A speculative read of the slot line at the top of the trip through the scalar cache -- no `glc`, compiler-visible --
   // was tried: it returned stale bytes from before the launch's sentinel fill now and then, i.e. WRONG RESULTS; every
   // slot read therefore stays a `glc` load inside the bounded loop below.  profiles/r01d_fused_tuning.txt, item 6.)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #pragma unroll
       for (int g = 0; g < NL / LG; ++g) {
         ft_line line[LG];
-        const double* lp = p.slots + (uint64_t)gl * TEAM + g * (8 * LG);
+        const double* lp = p.slots + (uint64_t)gl * SL + g * (8 * LG);
         unsigned cnt = 0u;
         for (;;) {
           if (LG == 1) asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(line[0]) : "s"(lp) : "memory");
@@ -219,10 +222,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           // (readfirstlane: inline-asm results count as divergent, which would put these compares on the vector ALU)
           unsigned pending = 0u;
 #pragma unroll
-          for (int l = 0; l < LG; ++l)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              pending |= (unsigned)__builtin_amdgcn_readfirstlane((int)line[l][2 * j + 1]) == FT_SENTINEL_HI ? 1u : 0u;
+          for (int j = 0; j < MG; ++j)
+            pending |= (unsigned)__builtin_amdgcn_readfirstlane((int)line[j / 8][2 * (j % 8) + 1]) == FT_SENTINEL_HI ? 1u : 0u;
           if (pending == 0u) break;
           if (++cnt >= FT_SPIN_POLLS) {   // give up on the exchange for the rest of the launch: the launch is reported as
             dead = true;                  // timed out (p.err) and its results are discarded, so the values no longer matter
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           if (!(p.variant & 4)) __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int j = 0; j < 8 * LG; ++j) {                          // member order: deterministic
+        for (int j = 0; j < MG; ++j) {                              // member order: deterministic
           const double q = __hiloint2double(__builtin_amdgcn_readfirstlane((int)line[j / 8][2 * (j % 8) + 1]),
                                             __builtin_amdgcn_readfirstlane((int)line[j / 8][2 * (j % 8)]));
           zs = (g == 0 && j == 0) ? q : zs + q;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // team-mates must hit the poll budget, raise p.err and let the whole grid drain (no hang)
     const bool sabotage = (p.variant & 64) && team == 0 && mem == TEAM - 1 && r == r_begin;
     if (lane == 0 && live && !sabotage)
-      store_partial(p.slots + (uint64_t)grow(r) * TEAM + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+      store_partial(p.slots + (uint64_t)grow(r) * SL + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
   };
   auto dot_row = [&](const d2 (&buf)[PPT]) -> double {
     double part = 0.0;
@@ -272,10 +273,14 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   if (p.accel) {
     double w1[1] = {v[6]};
     block_reduce<1>(w1, s_scr, 1);
-    if (tid == 0) store_partial(p.slots + (uint64_t)(p.mp + team) * TEAM + mem, w1[0]);
-    if (wave == 0) {
-      const double t = poll_line(p.mp + team, true);
-      if (lane == 0) s_bc[1] = t;
+    if (TEAM == 1) {                // a team of one holds the whole dot already
+      if (tid == 0) s_bc[1] = w1[0];
+    } else {
+      if (tid == 0) store_partial(p.slots + (uint64_t)(p.mp + team) * SL + mem, w1[0]);
+      if (wave == 0) {
+        const double t = poll_line(p.mp + team, true);
+        if (lane == 0) s_bc[1] = t;
+      }
     }
     ft_lds_barrier();
     rdot = s_bc[1];
@@ -287,7 +292,36 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // lane-0 branch it made hipcc drain vmcnt(0) -- all prefetched rows -- at the branch's join on every trip
   const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
 
-  if constexpr (!PIPE) {
+  if constexpr (TEAM == 1) {
+    // ---- a workgroup owns whole rows (n <= 4096): no exchange at all.  One barrier per trip: the wave partials are
+    // double-buffered by trip parity, every thread sums them and evaluates the row's gradient factor itself.
+    if (r_begin < r_end) {
+      constexpr int NB = PPT >= 8 ? 5 : 6;
+      d2 B[NB][PPT];
+      const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+#pragma unroll
+      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+      for (uint32_t t = 0; t < trips; t += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const uint32_t r = r_begin + t + j;
+          const bool live = r < r_end;
+          const uint32_t gr = grow(min(r, r_last));
+          const double bi = bq[gr];
+          const double za = p.accel ? zq[gr] : 0.0;
+          load_row(B[(j + NB - 1) % NB], min(r + (NB - 1u), r_last));
+          const double d = dot_row(B[j]);
+          const int par = (t + j) & 1u;
+          if (lane == 0) s_part2[par][wave] = d;
+          ft_lds_barrier();
+          const double zs = ((s_part2[par][0] + s_part2[par][1]) + s_part2[par][2]) + s_part2[par][3];
+          const double rv = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
+          if (tid == 0 && live) store_partial(p.z + gr, zs);
+          update_row(B[j], rv);
+        }
+      }
+    }
+  } else if constexpr (!PIPE) {
     // ---- exchange in line: prefetch r+2 | dot r | exchange r | update r  (two rows in flight during the exchange)
     auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
       load_row(nbuf, min(nr, r_last));

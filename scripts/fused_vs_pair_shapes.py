@@ -5,8 +5,9 @@ import numpy as np
 import fasta_python_amd as fa
 from fasta_python_amd import hip, synthetic
 
-for m, n in ((64, 65536), (256, 65536), (1024, 65536), (4096, 65536), (256, 32768), (1024, 32768), (4096, 32768),
-             (512, 16384), (2048, 16384), (8192, 16384), (16384, 16384)):
+shapes_tall = ((1048576, 1024), (262144, 2048), (262144, 4096), (65536, 4096), (16384, 4096), (4096, 4096), (131072, 8192), (16384, 8192), (65536, 12000))
+for m, n in (shapes_tall if len(sys.argv) > 1 and sys.argv[1] == "tall" else ((64, 65536), (256, 65536), (1024, 65536), (4096, 65536), (256, 32768), (1024, 32768), (4096, 32768),
+             (512, 16384), (2048, 16384), (8192, 16384), (16384, 16384))):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)

@@ -243,7 +243,7 @@ def test_lost_partial_times_out_instead_of_hanging_and_the_solver_falls_back():
     try:
         np.random.seed(4)
         ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=False, **opts)
-        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 64)
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8 | 64)       # bit 8: the 8-member shape (n = 4096 runs without any exchange by default)
         c = _state(op, b, 0.02, np.zeros(n))
         t0 = time.time()
         with pytest.raises(hip.HipError):
