@@ -14,6 +14,7 @@ Iterates, gradients and residual vectors never leave HBM unless `record_iterates
 There is NO CPU fallback: operands that are not device-recognised raise TypeError (see `_recognise`).
 """
 
+import math
 import warnings
 from time import time
 
@@ -28,6 +29,12 @@ __all__ = ["fasta", "Convergence", "FBSolver", "EPSILON"]
 
 PAIR_MAX_ELEMENTS = 1 << 26     # dense operators up to 64 Mi elements (<= ~0.1 ms per launch) take K-fwd + K-adj under one sync
 EPSILON = 1E-12      # fasta/__init__.py:32
+
+
+def _sqrt(x):
+    """sqrt of a device sum of squares as np.float64: same IEEE result as np.sqrt on the scalar, a fraction of its call cost
+    (the arguments are sums of squares or NaN, never negative)."""
+    return np.float64(math.sqrt(x))
 
 
 class Convergence:
@@ -235,8 +242,8 @@ class FBSolver:
         f1 = fval(s[hip.S_FSQ])
         bt = 0
         if self.backtrack:                                              # :195-217
-            M = np.max(self.f_hist[max(i - self.window + 1, 0):(i + 1)])
-            while (f1 - (M + s[hip.S_DXG0] + np.sqrt(s[hip.S_DX2]) ** 2 / (2 * tau)) > EPSILON
+            M = self.f_hist[max(i - self.window + 1, 0):(i + 1)].max()     # (ndarray.max: np.max's wrapper costs 3 us per call)
+            while (f1 - (M + s[hip.S_DXG0] + _sqrt(s[hip.S_DX2]) ** 2 / (2 * tau)) > EPSILON
                    and bt < self.max_backtracks):
                 tau *= self.stepsize_shrink
                 # :207-213: K-fwd again (a speculative K-adj, if any, is void) -- or the one-pass kernel again where it
@@ -267,18 +274,18 @@ class FBSolver:
             xh2, gsum, gmax = s[hip.S_XH2], s[hip.S_GSUM], s[hip.S_GMAX]
 
         tau_next = tau                                                  # :249
-        dx_norm = np.sqrt(s[hip.S_DX2])
+        dx_norm = _sqrt(s[hip.S_DX2])
         if self.adaptive:                                               # :253-270
             dot = a[hip.S_DXDG]
             tau_s = dx_norm ** 2 / dot
-            tau_m = max(dot / np.sqrt(a[hip.S_DG2]) ** 2, 0)
+            tau_m = max(dot / _sqrt(a[hip.S_DG2]) ** 2, 0)
             tau_next = tau_m if 2 * tau_m > tau_s else tau_s - .5 * tau_m
             if tau_next <= 0 or np.isinf(tau_next) or np.isnan(tau_next):
                 tau_next = tau * 1.5
         self.tau_next = tau_next
 
         self.residuals[i] = dx_norm / tau                               # :272
-        normalizer = max(np.sqrt(s[hip.S_G02]), np.sqrt(xh2) / tau) + EPSILON      # :274
+        normalizer = max(_sqrt(s[hip.S_G02]), _sqrt(xh2) / tau) + EPSILON          # :274
         self.stepsizes[i] = tau
         self.norm_residuals[i] = self.residuals[i] / normalizer
         self.f_hist[i + 1] = f1
