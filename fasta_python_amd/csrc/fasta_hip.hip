@@ -848,7 +848,8 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR; p.variant = c->fused_variant;
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
-  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
+  if (sh.team > 1)       // a team of one exchanges nothing: no slot line is ever read
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
   if (sh.team == 1) {
     switch (sh.ppt) {
