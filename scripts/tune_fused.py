@@ -28,7 +28,7 @@ for rnd in range(2):
     for variant in (2, 10):
         ctx.set_tuning(hip.TUNE_FUSED_VARIANT, variant)
         t = timed(lambda: ctx.step(0.2), hip.K_FUSED)
-        print(f"round {rnd} variant {variant} (defer={variant & 1} xcd={(variant >> 1) & 1} prefetch_deferred={variant & 1}): "
+        print(f"round {rnd} variant {variant} (same-XCD teams={(variant >> 1) & 1} legacy 8-member shape={(variant >> 3) & 1} cyclic rows={(variant >> 5) & 1}): "
               f"{t:7.3f} ms  moves {m * n * 8 / t / 1e6:6.0f} GB/s  algorithmic {2 * m * n * 8 / t / 1e6:6.0f} GB/s", flush=True)
 ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2)
 ctx.step(0.2); ctx.commit()
