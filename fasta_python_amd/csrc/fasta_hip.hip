@@ -148,6 +148,7 @@ struct fh_ctx {
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
+  int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
@@ -348,7 +349,9 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_NT:
       c->tv_nt = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_VARIANT:
-      c->fused_variant = (int)value; return 0;
+      c->fused_variant = (int)(value & 0xFFFF);
+      if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
+      return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
   }
 }
@@ -833,6 +836,12 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   FusedP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.nteams = (uint32_t)(c->ncu / sh.team);
+  // few rows: fewer teams (at least FUSED_MIN_ROWS rows each when possible, and a multiple of 8 teams so that the members of
+  // a team stay on one XCD): a smaller grid barrier and fewer g1 partials to sum in the epilogue
+  if (c->fused_min_rows > 0) {
+    const uint64_t want = std::max<uint64_t>(8, round_up((c->mp + c->fused_min_rows - 1) / c->fused_min_rows, 8));
+    p.nteams = (uint32_t)std::min<uint64_t>(p.nteams, want);
+  }
   p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
   p.x0 = io.x0; p.g0 = io.g0; p.xhat = io.xhat; p.xp = io.xp;
   p.b = c->b; p.z = io.z; p.tau = tau; p.loss = c->loss_kind; p.mode = io.mode;
