@@ -288,3 +288,32 @@ def test_on_device_spectral_norm_matches_numpy(shape):
         assert c.iteration_count == 30 and np.all(np.isfinite(c.residuals[:30]))
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("m,n", [(37, 100), (512, 1024), (3000, 2000)])
+def test_fwd_adj_under_one_sync_equals_fwd_then_adj(m, n):
+    """fh_fwd_adj enqueues K-fwd and K-adj back to back: same launches, same bits, one synchronisation."""
+    rng = np.random.RandomState(m)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap(A)
+    try:
+        c = op.ctx
+
+        def state():
+            c.set_loss_lsq(rng.randn(m) * 0 + 1.0); c.set_prox(hip.PROX_SHRINK, 0.03); c.set_vector(hip.VEC_X0, np.linspace(-1, 1, n)); c.init()
+
+        state()
+        s = c.fwd(0.3)
+        a = c.adj(0.3)
+        g = c.get_vector(hip.VEC_G1, n)
+        state()
+        p = c.fwd_adj(0.3)
+        assert np.array_equal(p[:8], s[:8]) and np.array_equal(p[8:14], a[8:14])
+        assert np.array_equal(c.get_vector(hip.VEC_G1, n), g)
+        # the solver takes this path by itself on short launches
+        ls, reg = fa.LeastSquares(np.ones(m)), fa.Shrink(0.03)
+        solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, max_iters=15, tolerance=0.0)
+        solver.setup().run()
+        assert solver.mode == "pair" and solver.pair_steps > 0
+    finally:
+        op.close()
