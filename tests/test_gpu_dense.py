@@ -166,7 +166,7 @@ def test_unrecognised_operands_fail_loudly():
         fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5))
 
 
-@pytest.mark.parametrize("m,n", [(4096, 4096), (16384, 2048)])
+@pytest.mark.parametrize("m,n", [(4096, 4096), (16384, 2048), (3000, 20000), (16384, 16384)])      # 4096^2 and 16384^2
 def test_mid_size_matches_oracle_loop(m, n):
     """Synthetic LASSO: HIP loop vs oracle loop on the same (device-generated) matrix, every iteration."""
     scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
@@ -176,7 +176,7 @@ def test_mid_size_matches_oracle_loop(m, n):
         x_true = pr.synth_sparse_signal(n, 1)
         b = A @ x_true + 0.01 * np.random.RandomState(2).randn(m)
         ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
-        opts = dict(tolerance=1e-6, max_iters=60, evaluate_objective=True, record_iterates=True)
+        opts = dict(tolerance=1e-6, max_iters=40 if m * n > 2 ** 27 else 60, evaluate_objective=True, record_iterates=True)
         np.random.seed(3)
         got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, **opts)
         P = pr.sparse_least_squares_from(A, b, 0.02)
