@@ -4,17 +4,26 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one FBS iteration of the product solver (fasta_python_amd.FBSolver.step): one K-fwd
-launch + one K-adj launch (+ one K-fwd per backtrack) over a device-resident synthetic matrix.
-N = 1: BASELINE.json configs[1], A = 65536 x 65536 float64 (32 GiB).  N > 1: the SAME matrix
-row-sharded over N ranks (one process per GPU, strong scaling), one RCCL all-reduce of the A^T
-partial sums per iteration; torch.distributed (gloo) is used only for rendezvous and barriers.
+One "step" = one FBS iteration of the product solver (fasta_python_amd.FBSolver.step) over a device-resident
+synthetic matrix: by default ONE launch of the one-pass kernel (both directions from a single read of A);
+`--fused off` gives the north-star structure of one K-fwd + one K-adj launch (+ one K-fwd per backtrack).
+N = 1: BASELINE.json configs[1], A = 65536 x 65536 float64 (32 GiB).  N > 1: the SAME matrix row-sharded
+over N ranks (one process per GPU, strong scaling), one RCCL all-reduce of the A^T partial sums per
+iteration; torch.distributed (gloo) is used only for rendezvous and barriers.  `--gpus N` without a
+torch.distributed.run environment makes this script start its own N workers (as a child process, before
+anything touches HIP) and relay rank 0's line.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+Prints ONE JSON line (rank 0): the driver's contract fields, `roofline` (achieved = the bytes the EXECUTED
+algorithm must move / the dominant kernel's HIP-event time, so frac <= 1), `cpu_baseline`, and `extra`:
+the other BASELINE configs timed by the same code in the same process -- nnls (config 3), tv and
+tv_accelerated (config 4), lasso_two_launch (the two-launch structure), and for N > 1 `config5_shard`
+(32768 rows per rank = BASELINE config 5's per-GPU shape).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
@@ -23,16 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-
-# the HIP library is loaded before anything else that might pull a second HIP runtime into the process
-import fasta_python_amd as fa
-from fasta_python_amd import hip, synthetic
-
 HBM_PEAK_GBS = 8000.0     # MI355X spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+FUSED_OPT = {"auto": "auto", "on": True, "off": False}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -41,14 +45,41 @@ def parse():
     ap.add_argument("--cols", dest="n", type=int, default=65536)
     ap.add_argument("--workload", default="lasso", choices=["lasso", "nnls", "tv"],
                     help="lasso = BASELINE config 2 (default, the headline); nnls = config 3; tv = config 4 (8192^2 image)")
-    ap.add_argument("--image", type=int, default=8192, help="TV image side (workload tv)")
+    ap.add_argument("--image", type=int, default=8192, help="TV image side (workload tv and the tv sub-results)")
+    ap.add_argument("--accelerate", action="store_true", help="FISTA (workload tv / lasso / nnls)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=8192)
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--no-extra", action="store_true", help="skip the nnls / tv / two-launch sub-results")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of A the CPU baseline runs on (0 = all)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--tune", default="", help="comma list key=value of FH_TUNE_* integers, e.g. 3=2,0=8")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"],
                     help="one-pass iteration kernel (fh_step): auto = when the shape supports it")
-    return ap.parse_args()
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rendezvous, broadcast, barrier and max-over-ranks only -- no GPU work (CPU rehearsal of --gpus N)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# multi-process plumbing
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell: start N workers under torch.distributed.run as a CHILD process
+    (this process has made no HIP call and makes none) and let rank 0 print the line on the inherited stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 class Group:
@@ -65,7 +96,17 @@ class Group:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            os.environ.setdefault("MASTER_PORT", "29511")
+            # gloo announces its peers on the C-level stdout; the driver reads ONE JSON line there, so park fd 1 on stderr
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
             self.dist, self.torch = dist, torch
 
     def barrier(self):
@@ -91,35 +132,68 @@ class Group:
             self.dist.destroy_process_group()
 
 
-def cpu_baseline(A_map, b, mu, n, m_total, sample_rows, iters):
-    """The NumPy oracle loop (oracle/fasta_np.py, parity-pinned to the reference) on the first
-    `sample_rows` rows of the same matrix, on this box's host cores; scaled to the full row count."""
-    from oracle import fasta_np as fo
-    from oracle import problems as pr
-    rows = min(sample_rows, A_map.Wshape[0])
-    A = A_map.host_rows(0, rows)
-    P = pr.sparse_least_squares_from(A, b[:rows], mu)
-    np.random.seed(3)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        c = fo.fasta(*P.args7(), max_iters=iters, tolerance=0.0)
-    dt = c.times[c.iteration_count] - c.times[0]
-    it_s_sample = c.iteration_count / dt
+def plumbing_only(args, grp):
+    """CPU rehearsal of the N-rank launch: everything bench.py does between ranks except the GPU work."""
+    token = grp.broadcast_bytes(bytes(range(128)) if grp.rank == 0 else None)
+    assert token == bytes(range(128))
+    grp.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (grp.rank + 1))
+    grp.barrier()
+    elapsed = grp.max(time.perf_counter() - t0)
+    if grp.rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": grp.world, "ranks": grp.world, "max_elapsed_s": elapsed,
+                          "rows_per_rank": args.m // grp.world}))
+    grp.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle is the checker / the baseline, never the product)
+# ------------------------------------------------------------------------------------------------------------
+def _blas_info():
     try:
         from threadpoolctl import threadpool_info
         blas = [d for d in threadpool_info() if d.get("user_api") == "blas"]
-        threads = int(blas[0]["num_threads"]) if blas else (os.cpu_count() or 1)
-        blas_name = (blas[0].get("internal_api", "?") + " " + str(blas[0].get("version", ""))) if blas else "?"
+        if blas:
+            return int(blas[0]["num_threads"]), blas[0].get("internal_api", "?") + " " + str(blas[0].get("version", ""))
     except Exception:
-        threads, blas_name = os.cpu_count() or 1, "?"
+        pass
+    return os.cpu_count() or 1, "?"
+
+
+def cpu_baseline(A_map, b, mu, n, m_total, rows, iters, repeats):
+    """The NumPy oracle loop (oracle/fasta_np.py, parity-pinned to the reference) on this box's host cores, on the same
+    matrix pulled back from HBM -- all rows by default -- `repeats` times; the median rate is reported."""
+    import numpy as np
+    from oracle import fasta_np as fo
+    from oracle import problems as pr
+    rows = min(rows or m_total, A_map.Wshape[0])
+    t0 = time.perf_counter()
+    A = A_map.host_rows(0, rows)
+    pull_s = time.perf_counter() - t0
+    P = pr.sparse_least_squares_from(A, b[:rows], mu)
+    rates, passes = [], None
+    for _ in range(repeats):
+        np.random.seed(3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = fo.fasta(*P.args7(), max_iters=iters, tolerance=0.0)
+        rates.append(c.iteration_count / (c.times[c.iteration_count] - c.times[0]))
+        passes = c.passes
+    rates.sort()
+    median = rates[len(rates) // 2]
+    threads, blas_name = _blas_info()
+    scaled = "" if rows == m_total else f", scaled by {rows}/{m_total}"
     return {
-        "value": it_s_sample * rows / m_total,
+        "value": median * rows / m_total,
         "unit": "iterations/s",
         "cores": threads,
         "kind": "port",
-        "sample": (f"oracle NumPy loop ({blas_name}), {c.iteration_count} iterations on rows 0..{rows} of the same "
-                   f"{m_total}x{n} matrix ({it_s_sample:.3f} it/s on the sample, scaled by {rows}/{m_total}; "
-                   f"passes A={c.passes['A']} AH={c.passes['AH']} incl. setup are outside the timed span)"),
+        "runs": [r * rows / m_total for r in rates],
+        "sample": (f"oracle NumPy loop ({blas_name}, {threads} BLAS threads, {os.cpu_count()} logical CPUs), median of {repeats} runs of "
+                   f"{iters} iterations each on rows 0..{rows} of the same {m_total}x{n} float64 matrix{scaled}; "
+                   f"per run A passes={passes['A']} AH={passes['AH']} incl. the setup passes, which lie outside the timed span "
+                   f"(times[k]-times[0], as the reference's print_info derives it); D2H of the matrix took {pull_s:.1f} s"),
     }
 
 
@@ -137,8 +211,108 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def run_tv(args, grp):
+# ------------------------------------------------------------------------------------------------------------
+# timed loops
+# ------------------------------------------------------------------------------------------------------------
+def timed_steps(solver, ctx, grp, warmup, steps):
+    """W untimed + exactly K timed solver steps between barrier + device sync on both sides; max over ranks."""
+    import numpy as np
+    from fasta_python_amd import hip
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        solver.setup()
+        for _ in range(warmup):
+            solver.step()
+        ctx.timing_reset()
+        ctx.timing_enable(True)
+        bt0 = solver.total_backtracks
+        fs0 = solver.fused_steps
+        grp.barrier(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver.step()
+        ctx.sync(); grp.barrier()
+        t1 = time.perf_counter()
+        ctx.timing_enable(False)
+    elapsed = grp.max(t1 - t0)
+    k = {name: ctx.timing_get(kid) for name, kid in
+         (("fwd", hip.K_FWD), ("adj", hip.K_ADJ), ("comm", hip.K_COMM), ("fused", hip.K_FUSED), ("aux", hip.K_AUX))}
+    return {"elapsed": elapsed, "backtracks": solver.total_backtracks - bt0, "fused_steps": solver.fused_steps - fs0, "k": k}
+
+
+def kernel_table(per):
+    """per: name -> (total_ms, launches, algorithmic bytes per launch).  Returns (dominant name, table)."""
+    per = {k: v for k, v in per.items() if v[1]}
+    table = {k: {"launches": v[1], "avg_ms": v[0] / v[1], "algorithmic_bytes_per_launch": v[2],
+                 "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9} for k, v in per.items()}
+    dom = max(per, key=lambda k: per[k][0]) if per else None
+    return dom, table
+
+
+def dense_bytes(m, n):
+    """Algorithmic HBM bytes per launch of the three dense kernels (SURVEY.md 8(d) vector terms):
+    K-fwd reads A, x0, g0, b and writes xhat, xprox, z; K-adj reads A, z, b, x0, xprox, xhat, g... ; the one-pass kernel
+    reads A ONCE and moves the union of both vector sets (3m + 7n)."""
+    return {"fwd": (m * n + 4 * n + 2 * m) * 8, "adj": (m * n + 2 * m + 5 * n) * 8, "fused": (m * n + 3 * m + 7 * n) * 8}
+
+
+def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False):
+    """One dense workload (LASSO or NNLS) on the resident matrix `A` (this rank's row block)."""
+    import numpy as np
+    import fasta_python_amd as fa
+    from fasta_python_amd import synthetic
+    ctx = A.ctx
+    m_local = A.Wshape[0]
+    row0 = A.rows[0]
+    mu, sigma = 0.02, (0.005 if workload == "nnls" else 0.01)     # nn_least_squares.py:49 uses 0.005
+    x_true = synthetic.sparse_signal(n, seed=1)
+    b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
+    loss = fa.LeastSquares(b)
+    reg = fa.Shrink(mu) if workload == "lasso" else fa.NonNeg()
+    solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not accelerate, accelerate=accelerate, verbose=False,
+                         max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
+    np.random.seed(3)           # same Lipschitz probes on every rank
+    t = timed_steps(solver, ctx, grp, warmup, steps)
+    by = dense_bytes(m_local, n)
+    per = {"fasta_fwd(k_fwd_dense)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_dense)": t["k"]["adj"] + (by["adj"],),
+           "fasta_step(k_fused_dense)": t["k"]["fused"] + (by["fused"],)}
+    dom, table = kernel_table(per)
+    loop_bytes = sum(v[1] * v[2] for v in per.values())
+    # SURVEY.md 8(d) prices every iteration at TWO passes over A (N_A = iters + backtracks, N_AH = iters)
+    model_bytes = ((steps + t["backtracks"]) * by["fwd"] + steps * by["adj"])
+    comm_ms, comm_cnt = t["k"]["comm"]
+    return {
+        "value": steps / t["elapsed"], "ms_per_step": t["elapsed"] / steps * 1e3, "elapsed": t["elapsed"],
+        "backtracks": t["backtracks"], "fused_steps": t["fused_steps"], "dominant": dom, "per_kernel": table,
+        "loop_GB/s_wallclock": loop_bytes / t["elapsed"] / 1e9,
+        "vs_two_pass_model": {"bytes_per_iteration": by["fwd"] + by["adj"], "GB/s": model_bytes / t["elapsed"] / 1e9,
+                              "frac": model_bytes / t["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                              "note": "SURVEY.md 8(d) byte model (A read twice per iteration) / wall-clock: exceeds the spec peak "
+                                      "when the one-pass kernel reads A once"},
+        "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None, "comm_launches": comm_cnt,
+        "solver": solver, "b": b, "mu": mu,
+    }
+
+
+def sub_result(r, workload):
+    d = r["per_kernel"].get(r["dominant"], {}) if r["dominant"] else {}
+    return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
+            "backtracks_in_timed_steps": r["backtracks"], "kernel": r["dominant"], "avg_launch_ms": d.get("avg_ms"),
+            "achieved_GB/s": d.get("GB/s"), "frac": d.get("GB/s") / HBM_PEAK_GBS if d else None,
+            "per_kernel": r["per_kernel"]}
+
+
+def tv_bytes(P, accelerate):
+    """Algorithmic bytes per launch of the stencil kernels as executed: the gradient is never
+    materialised.  One-pass: reads x0 16 + z_cur 8 + b 8, writes xprox 16 + z_new 8 per pixel; with FISTA the iterate and
+    its image are kept as (prox output, previous prox output, coefficient): reads 2x16 + 2x8 + 8, writes 16 + 8."""
+    return {"fwd": 56 * P, "adj": (56 + (48 if accelerate else 0)) * P, "fused": (80 if accelerate else 56) * P}
+
+
+def run_tv(args, grp, steps, warmup, fused, accelerate):
     """BASELINE config 4: TV denoising dual on an image of side --image, 1 GPU."""
+    import numpy as np
+    import fasta_python_amd as fa
     from fasta_python_amd.examples.tv_denoising import checkerboard
     side = args.image
     np.random.seed(7)
@@ -146,168 +320,170 @@ def run_tv(args, grp):
     M += 0.1 * np.random.standard_normal(M.shape)
     mu = 0.1
     A = fa.GradDivMap(M.shape, device=grp.local_rank)
-    ctx = A.ctx
-    loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
-    total = args.warmup + args.steps
-    solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=True, accelerate=False, verbose=False,
-                         max_iters=total, tolerance=0.0, fused={"auto": "auto", "on": True, "off": False}[args.fused])
-    np.random.seed(3)
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        solver.setup()
-        for _ in range(args.warmup):
-            solver.step()
-        ctx.timing_reset(); ctx.timing_enable(True)
-        bt0 = solver.total_backtracks
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            solver.step()
-        ctx.sync()
-        t1 = time.perf_counter()
-        ctx.timing_enable(False)
-    elapsed = t1 - t0
+    try:
+        loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=not accelerate, accelerate=accelerate,
+                             verbose=False, max_iters=warmup + steps, tolerance=0.0, fused=fused)
+        np.random.seed(3)
+        t = timed_steps(solver, A.ctx, grp, warmup, steps)
+    finally:
+        A.close()
     P = side * side
-    fwd_ms, fwd_cnt = ctx.timing_get(hip.K_FWD)
-    adj_ms, adj_cnt = ctx.timing_get(hip.K_ADJ)
-    fus_ms, fus_cnt = ctx.timing_get(hip.K_FUSED)
-    per = {"fasta_fwd(k_fwd_tv_step)": (fwd_ms, fwd_cnt, 64 * P), "fasta_adj(k_adj_tv_step)": (adj_ms, adj_cnt, 72 * P),
-           "fasta_step(k_fused_tv_step)": (fus_ms, fus_cnt, 136 * P)}
-    per = {k: v for k, v in per.items() if v[1]}
-    dom = max(per, key=lambda k: per[k][0])
-    dms, dcnt, dbytes = per[dom]
-    achieved = dbytes / (dms / dcnt * 1e-3) / 1e9
-    result = {
-        "metric": "FBS iterations/sec, TV denoising dual (div/grad stencil, unit-ball prox)",
-        "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), adaptive FBS with backtracking",
-                   "backtracks_in_timed_steps": solver.total_backtracks - bt0, "parallelism": "1 GPU"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("k_fused_tv_step" if "fused" in dom else ("k_fwd_tv_step" if "fwd" in dom else "k_adj_tv_step"))[0]
-                     if side == 8192 else None,
-                     "kernel": dom,
-                     "avg_launch_ms": dms / dcnt, "algorithmic_bytes_per_launch": dbytes,
-                     "note": "priced at the materialised-vector model of SURVEY.md 8(d) (64*P / 72*P); this build never "
-                             "materialises the gradient: the two step kernels move 56*P each, the one-pass kernel ~60*P for both (fh_tv.h)",
-                     "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1], "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9}
-                                    for k, v in per.items() if v[1]},
-                     "loop_GB/s_wallclock": (fwd_cnt * 64 * P + adj_cnt * 72 * P + fus_cnt * 136 * P) / elapsed / 1e9},
+    by = tv_bytes(P, accelerate)
+    per = {"fasta_fwd(k_fwd_tv_step)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_tv_step)": t["k"]["adj"] + (by["adj"],),
+           "fasta_step(k_fused_tv_step)": t["k"]["fused"] + (by["fused"],)}
+    dom, table = kernel_table(per)
+    model_bytes = (steps * 136 + t["backtracks"] * 64) * P
+    return {
+        "value": steps / t["elapsed"], "ms_per_step": t["elapsed"] / steps * 1e3, "elapsed": t["elapsed"],
+        "backtracks": t["backtracks"], "fused_steps": t["fused_steps"], "dominant": dom, "per_kernel": table,
+        "loop_GB/s_wallclock": sum(v[1] * v[2] for v in per.values()) / t["elapsed"] / 1e9,
+        "vs_materialised_model": {"bytes_per_iteration": 136 * P, "GB/s": model_bytes / t["elapsed"] / 1e9,
+                                  "frac": model_bytes / t["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                                  "note": "SURVEY.md 8(d) materialised-vector model (136*P per iteration + 64*P per backtrack) / wall-clock"},
+        "side": side,
     }
-    print(json.dumps(result))
-    A.close()
 
 
-def main():
-    args = parse()
+def tv_line(args, r, accelerate):
+    d = r["per_kernel"][r["dominant"]]
+    side = r["side"]
+    return {
+        "metric": "FBS iterations/sec, TV denoising dual (div/grad stencil, unit-ball prox)",
+        "value": r["value"], "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), {'FISTA' if accelerate else 'adaptive FBS'} with backtracking",
+                   "backtracks_in_timed_steps": r["backtracks"], "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GB/s"] / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("k_fused_tv_step" if "fused" in r["dominant"] else
+                                            ("k_fwd_tv_step" if "fwd" in r["dominant"] else "k_adj_tv_step"))[0] if side == 8192 else None,
+                     "kernel": r["dominant"], "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                     "per_kernel": r["per_kernel"], "loop_GB/s_wallclock": r["loop_GB/s_wallclock"],
+                     "vs_materialised_model": r["vs_materialised_model"]},
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("FASTA_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(self_launch(args, argv))          # before any import that could initialise HIP
     grp = Group()
+    if grp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={grp.world}")
+    if args.plumbing_only:
+        return plumbing_only(args, grp)
+
+    import numpy as np
+    import fasta_python_amd as fa
+    from fasta_python_amd import hip, synthetic
+
+    fused = FUSED_OPT[args.fused]
     if args.workload == "tv":
         if grp.world != 1:
             raise SystemExit("the TV workload is single-GPU (BASELINE config 4)")
-        return run_tv(args, grp)
-    args.prox = "nonneg" if args.workload == "nnls" else "shrink"
-    if grp.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={grp.world}: launch with torch.distributed.run")
+        print(json.dumps(tv_line(args, run_tv(args, grp, args.steps, args.warmup, fused, args.accelerate), args.accelerate)))
+        return grp.close()
+
     m_total, n = args.m, args.n
     assert m_total % grp.world == 0
     m_local = m_total // grp.world
     row0 = grp.rank * m_local
-    mu, sigma = 0.02, (0.005 if args.workload == "nnls" else 0.01)     # nn_least_squares.py:49 uses 0.005
-
     tuning = {}
     for item in filter(None, args.tune.split(",")):
         k, v = item.split("=")
         tuning[int(k)] = int(v)
 
-    scale = synthetic.lasso_scale(m_total, n)
-    A = fa.DenseMatrixMap.synthetic(m_local, n, seed=0, scale=scale, row0=row0, m_total=m_total,
-                                    device=grp.local_rank, tuning=tuning)
+    def shard(m_all):
+        """This rank's row block of the synthetic (m_all x n) matrix, generated in HBM, with the RCCL communicator attached."""
+        rows = m_all // grp.world
+        A = fa.DenseMatrixMap.synthetic(rows, n, seed=0, scale=synthetic.lasso_scale(m_all, n), row0=grp.rank * rows,
+                                        m_total=m_all, device=grp.local_rank, tuning=tuning)
+        if grp.world > 1 or grp.force:
+            uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
+            A.ctx.comm_init(grp.world, grp.rank, uid)
+        return A
+
+    A = shard(m_total)
     ctx = A.ctx
-    if grp.world > 1 or grp.force:
-        uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
-        ctx.comm_init(grp.world, grp.rank, uid)
-
-    x_true = synthetic.sparse_signal(n, seed=1)
-    b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
-    loss = fa.LeastSquares(b)
-    reg = fa.Shrink(mu) if args.prox == "shrink" else fa.NonNeg()
-
-    total = args.warmup + args.steps
-    solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=True, accelerate=False, verbose=False,
-                         max_iters=total, tolerance=0.0, backtrack=True, evaluate_objective=False,
-                         fused={"auto": "auto", "on": True, "off": False}[args.fused])
-    np.random.seed(3)           # same Lipschitz probes on every rank
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        solver.setup()
-        for _ in range(args.warmup):
-            solver.step()
-        ctx.timing_reset()
-        ctx.timing_enable(True)
-        bt0 = solver.total_backtracks
-        grp.barrier(); ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            solver.step()
-        ctx.sync(); grp.barrier()
-        t1 = time.perf_counter()
-        ctx.timing_enable(False)
-    elapsed = grp.max(t1 - t0)
-    backtracks = solver.total_backtracks - bt0
-
-    fwd_ms, fwd_cnt = ctx.timing_get(hip.K_FWD)
-    adj_ms, adj_cnt = ctx.timing_get(hip.K_ADJ)
-    comm_ms, comm_cnt = ctx.timing_get(hip.K_COMM)
-    fus_ms, fus_cnt = ctx.timing_get(hip.K_FUSED)
-    # algorithmic bytes per launch (DESIGN.md section "byte model")
-    bytes_fwd = (m_local * n + 2 * n + m_local + 2 * n + m_local) * 8
-    bytes_adj = (m_local * n + 2 * m_local + 4 * n + n) * 8
-    per = {"fasta_fwd(k_fwd_dense)": (fwd_ms, fwd_cnt, bytes_fwd), "fasta_adj(k_adj_dense)": (adj_ms, adj_cnt, bytes_adj),
-           # one launch = both directions: priced at the two-pass algorithmic bytes of SURVEY.md 8(d); it MOVES half
-           "fasta_step(k_fused_dense)": (fus_ms, fus_cnt, bytes_fwd + bytes_adj)}
-    dom = max(per, key=lambda k: per[k][0])
-    dms, dcnt, dbytes = per[dom]
-    achieved = dbytes / (dms / dcnt * 1e-3) / 1e9 if dcnt else 0.0
-    loop_bytes = fwd_cnt * bytes_fwd + adj_cnt * bytes_adj + fus_cnt * (bytes_fwd + bytes_adj)
+    ranks_seen = ctx.comm_count()
+    main_r = run_dense(args, grp, A, m_total, n, args.workload, fused, args.steps, args.warmup, args.accelerate)
+    dom = main_r["dominant"]
+    d = main_r["per_kernel"][dom]
     traffic, traffic_src = (pmc_traffic("k_fused_dense" if "fused" in dom else ("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>"))
                             if (m_total, n, grp.world) == (65536, 65536, 1) else (None, None))
-    ceil_ms, ceil_bytes = ctx.stream_read_ms(2)
+    ceil_ms, ceil_bytes = ctx.stream_read_ms(3)
+    fused_kind = ctx.fused_supported()
 
+    names = {"lasso": ("LASSO", "soft-threshold"), "nnls": ("NNLS", "non-negativity")}[args.workload]
     result = {
         "metric": "FBS iterations/sec + achieved HBM GB/s, dense A m=n=65536, LASSO prox",
-        "value": args.steps / elapsed,
+        "value": main_r["value"],
         "unit": "iterations/s",
         "n_gpus": grp.world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": main_r["ms_per_step"],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{'NNLS' if args.workload == 'nnls' else 'LASSO'} dense A {m_total}x{n} float64, "
-                               f"{'non-negativity' if args.workload == 'nnls' else 'soft-threshold'} prox, adaptive FBS with backtracking"
+        "config": {"workload": f"{names[0]} dense A {m_total}x{n} float64, {names[1]} prox, "
+                               f"{'FISTA' if args.accelerate else 'adaptive FBS'} with backtracking"
                                + (f", row-sharded over {grp.world} GPUs ({m_local} rows each)" if grp.world > 1 else ""),
-                   "m": m_total, "n": n, "prox": args.prox, "mu": mu, "backtracks_in_timed_steps": backtracks,
+                   "m": m_total, "n": n, "prox": "shrink" if args.workload == "lasso" else "nonneg", "mu": main_r["mu"],
+                   "backtracks_in_timed_steps": main_r["backtracks"],
+                   "iteration_structure": ("one launch per iteration (one-pass kernel: both directions from a single read of A)"
+                                           if main_r["fused_steps"] else "two launches per iteration (K-fwd, K-adj)"),
+                   "fused_supported": fused_kind,        # 0 = this shape has no one-pass kernel (two passes over A per iteration)
                    "parallelism": f"row-shard x{grp.world}" if grp.world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "stream_read_ceiling_GB/s": ceil_bytes / ceil_ms / 1e6,
-                     "kernel": dom, "avg_launch_ms": dms / dcnt if dcnt else None,
-                     "algorithmic_bytes_per_launch": dbytes,
-                     "per_kernel": {k: {"launches": v[1], "avg_ms": v[0] / v[1] if v[1] else None,
-                                        "GB/s": v[2] / (v[0] / v[1] * 1e-3) / 1e9 if v[1] else None} for k, v in per.items()},
-                     "loop_GB/s_wallclock": loop_bytes / elapsed / 1e9,
-                     "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None,
-                     "fused_one_pass_steps": solver.fused_steps,
-                     "note": ("achieved = algorithmic (two-pass) bytes / launch time; the fused one-pass kernel reads A once, "
-                              "so its HBM traffic is about half of algorithmic_bytes_per_launch" if "fused" in dom else None)},
+                     "stream_read_probe": "k_stream_probe<8,1>: K-fwd's launch shape (8-row groups, <=2 persistent workgroups/CU, "
+                                          "16 non-temporal 16-byte loads in flight per lane), loads + adds only",
+                     "per_kernel": main_r["per_kernel"],
+                     "loop_GB/s_wallclock": main_r["loop_GB/s_wallclock"],
+                     "vs_two_pass_model": main_r["vs_two_pass_model"],
+                     "comm_avg_ms": main_r["comm_avg_ms"], "comm_launches": main_r["comm_launches"],
+                     "ranks_seen": ranks_seen,
+                     "fused_one_pass_steps": main_r["fused_steps"],
+                     "note": "achieved = bytes the executed algorithm must move per launch (A once for the one-pass kernel, "
+                             "plus the 3m+7n vector terms) / HIP-event launch time"},
     }
-    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(A, b, mu, n, m_total, args.cpu_sample_rows, args.cpu_iters)
+
+    extra = {}
+    if not args.no_extra and not args.accelerate and args.workload == "lasso":
+        if fused is not False and main_r["fused_steps"]:
+            r = run_dense(args, grp, A, m_total, n, "lasso", False, args.steps, args.warmup)
+            extra["lasso_two_launch"] = sub_result(r, f"LASSO {m_total}x{n}, two launches per iteration (K-fwd + K-adj, the north-star structure)")
+        r = run_dense(args, grp, A, m_total, n, "nnls", fused, args.steps, args.warmup)
+        extra["nnls"] = sub_result(r, f"NNLS {m_total}x{n} (BASELINE config 3), non-negativity prox, same matrix")
+        if grp.world > 1:
+            # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
+            A.close()
+            A = shard(32768 * grp.world)
+            ctx = A.ctx
+            r = run_dense(args, grp, A, 32768 * grp.world, n, "lasso", fused, args.steps, args.warmup)
+            s = sub_result(r, f"LASSO {32768 * grp.world}x{n} row-sharded over {grp.world} GPUs, 32768 rows each "
+                              f"(BASELINE config 5 is this at 8 GPUs)")
+            s["comm_avg_ms"], s["ranks_seen"] = r["comm_avg_ms"], ctx.comm_count()
+            extra["config5_shard"] = s
+        else:
+            for key, acc in (("tv", False), ("tv_accelerated", True)):
+                r = run_tv(args, grp, args.steps, args.warmup, "auto", acc)
+                s = sub_result(r, f"TV denoising {args.image}x{args.image} (BASELINE config 4), "
+                                  f"{'FISTA (test_modes accelerated)' if acc else 'adaptive FBS'}")
+                s["vs_materialised_model"] = r["vs_materialised_model"]
+                extra[key] = s
+    if extra:
+        result["extra"] = extra
+    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline and args.workload == "lasso" and not args.accelerate:
+        result["cpu_baseline"] = cpu_baseline(A, main_r["b"], main_r["mu"], n, m_total, args.cpu_rows, args.cpu_iters, args.cpu_repeats)
     if grp.rank == 0:
         print(json.dumps(result))
     A.close()

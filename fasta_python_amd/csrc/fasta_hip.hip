@@ -54,6 +54,7 @@ struct RcclApi {
   int (*GetUniqueId)(fh_nccl_uid*) = nullptr;
   int (*CommInitRank)(fh_nccl_comm*, int, fh_nccl_uid, int) = nullptr;
   int (*CommDestroy)(fh_nccl_comm) = nullptr;
+  int (*CommCount)(const fh_nccl_comm, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, fh_nccl_comm, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -77,6 +78,7 @@ static int rccl_load() {
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
   SYM(AllReduce, "ncclAllReduce");
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
@@ -1226,6 +1228,13 @@ extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) 
   return 0;
 }
 
+extern "C" int fh_comm_count(fh_ctx* c, int* nranks) {
+  if (!c || !nranks) return fail(FH_E_ARG, "null argument");
+  *nranks = 1;                       // no communicator: a single-GPU context
+  if (c->comm) NCCL_TRY(g_rccl.CommCount(c->comm, nranks));   // what RCCL itself reports, not what the caller asked for
+  return 0;
+}
+
 extern "C" int fh_comm_destroy(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
   if (c->comm) {
@@ -1260,19 +1269,21 @@ extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint6
   FH_TRY(check_ready(c, false));
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "stream-read ceiling needs a dense matrix");
   if (reps < 1) reps = 1;
-  const uint64_t n2 = c->mp * c->ld / 2;
-  k_stream_read<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, n2, c->dscal + FH_NSCALARS + 2);   // warm-up
+  // same launch shape as K-fwd at this size: groups of 8 rows, <= 2 persistent workgroups per CU, non-temporal 16-byte loads
+  const uint32_t ld2 = (uint32_t)(c->ld / 2), nrg = (uint32_t)(c->mp / 8);
+  const unsigned grid = (unsigned)std::min<long long>(std::max<uint32_t>(nrg, 1u), c->fwd_cap > 0 ? c->fwd_cap : 512);
+  double* sink = c->dscal + FH_NSCALARS + 2;
+  k_stream_probe<8, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, ld2, nrg, sink);   // warm-up
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; ++i)
-    k_stream_read<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, n2, c->dscal + FH_NSCALARS + 2);
+  for (int i = 0; i < reps; ++i) k_stream_probe<8, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, ld2, nrg, sink);
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (ms_per_pass) *ms_per_pass = ms / reps;
-  if (bytes_per_pass) *bytes_per_pass = n2 * 16;
+  if (bytes_per_pass) *bytes_per_pass = (uint64_t)nrg * 8 * ld2 * 16;
   return 0;
 }

@@ -442,13 +442,34 @@ __global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len,
   }
 }
 
-// read-only streaming pass over A (the "achievable ceiling" next to the 8 TB/s spec peak)
-__global__ __launch_bounds__(FH_WG) void k_stream_read(const double* A, uint64_t n2, double* sink) {
-  const d2* p = reinterpret_cast<const d2*>(A);
-  d2 acc = {0.0, 0.0};
-  const uint64_t stride = (uint64_t)gridDim.x * FH_WG;
-  uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x;
-#pragma unroll 8
-  for (; i < n2; i += stride) acc += p[i];
-  if (acc.x + acc.y == 1.2345e300) sink[0] = acc.x;   // never true; keeps the loads alive
+// Read-only streaming pass over A, the "achievable ceiling" printed next to the 8 TB/s spec peak.  It is shaped like
+// the product's own row streams so that it bounds them: persistent workgroups (<= 2 per CU) grid-striding over groups of
+// R whole rows, every lane keeping 2*R non-temporal 16-byte loads in flight, nothing but an add per element -- K-fwd's
+// m-side loop with the x multiply, the prox recompute and every reduction removed.  (Round 1's probe used plain loads
+// from 8192 transient workgroups and topped out below K-fwd itself.)
+template <int R, int NT>
+__global__ __launch_bounds__(FH_WG) void k_stream_probe(const double* A, uint32_t ld2, uint32_t nrg, double* sink) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t ntrip = (ld2 + 2 * FH_WG - 1) / (2 * FH_WG);
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
+  for (uint32_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
+    const d2* Ab = reinterpret_cast<const d2*>(A) + (uint64_t)rg * R * ld2;
+    for (uint32_t t = 0; t < ntrip; ++t) {
+      const uint32_t c0 = t * (2 * FH_WG) + tid, c1 = c0 + FH_WG;
+      const uint32_t k0 = c0 < ld2 ? c0 : 0u, k1 = c1 < ld2 ? c1 : 0u;
+      d2 a0[R], a1[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a0[r] = load_stream<NT>(Ab + (uint64_t)r * ld2 + k0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) a1[r] = load_stream<NT>(Ab + (uint64_t)r * ld2 + k1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] += (a0[r].x + a0[r].y) + (a1[r].x + a1[r].y);
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s += acc[r];
+  if (s == 1.2345e300) sink[0] = s;   // never true; keeps the loads alive
 }

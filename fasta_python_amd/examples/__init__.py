@@ -1,16 +1,21 @@
-"""Working counterparts of the reference's example harness (fasta/examples/__init__.py:19-91), running on
-the MI355X path.  The reference's own example modules do not import; these keep
-their recipes -- same RNG draw order in `construct()`, same closures in `solve()`, same three-mode driver --
-with device-tagged operands, an optional `seed=` for reproducibility and no plotting dependency.
+"""Working counterparts of the reference's example harness (fasta/examples/__init__.py:19-91).  The reference's own
+example modules do not import; these keep their recipes -- same RNG draw order in `construct()`,
+same closures in `solve()`, same three-mode driver -- plus an optional `seed=` and no plotting dependency.
 
-    python -m fasta_python_amd.examples.sparse_least_squares
+Every problem takes `backend=`:
+    "hip"    device-tagged operands, the fused MI355X loop (raises without libfasta_hip.so / a GPU);
+    "numpy"  the reference's closures as written there, on the generic host loop (BASELINE config 1: no GPU needed).
+
+    python -m fasta.examples.sparse_least_squares [--backend hip|numpy]
+(without --backend the command line uses "hip" when a GPU is visible and says so when it is not).
 """
 
+import sys
 from abc import ABC, abstractmethod
 
 from .. import Convergence
 
-__all__ = ["ExampleProblem", "print_info", "test_modes", "TOLERANCE"]
+__all__ = ["ExampleProblem", "print_info", "test_modes", "cli_backend", "TOLERANCE"]
 
 TOLERANCE = 1E-5          # fasta/examples/__init__.py:16
 
@@ -30,10 +35,41 @@ class ExampleProblem(ABC):
     def plot(self, solution):
         """Presentation is out of scope for this build (reference: fasta/plots.py)."""
 
+    backend = "hip"
+    _device_op = None
+
+    def device_operator(self, make):
+        """The problem's operator in HBM, created on first use (backend "hip") and kept for later solves."""
+        if self._device_op is None:
+            self._device_op = make()
+        return self._device_op
+
     def close(self):
+        if self._device_op is not None:
+            self._device_op.close()
+            self._device_op = None
         A = getattr(self, "A", None)
         if hasattr(A, "close"):
             A.close()
+
+
+def cli_backend(argv=None):
+    """`--backend hip|numpy` of the example command lines.  Default: "hip" when a GPU is visible; otherwise "numpy",
+    announced -- an explicit choice of the harness, `fasta()` itself never falls back."""
+    argv = sys.argv[1:] if argv is None else argv
+    if "--backend" in argv:
+        choice = argv[argv.index("--backend") + 1]
+        if choice not in ("hip", "numpy"):
+            raise SystemExit("--backend must be hip or numpy")
+        return choice
+    from .. import hip
+    try:
+        if hip.device_count() > 0:
+            return "hip"
+    except Exception:
+        pass
+    print("no MI355X visible: running the generic NumPy host loop (--backend numpy)")
+    return "numpy"
 
 
 def print_info(solution: Convergence) -> None:

@@ -4,25 +4,33 @@ Recipe: fasta/examples/lasso.py:42-45 (closures), :51-79 (construct; mu is scale
 import numpy as np
 from numpy import linalg as la
 
-from .. import L1Ball, LeastSquares, LinearMap, fasta
-from . import ExampleProblem, test_modes
+from .. import DenseMatrixMap, L1Ball, LeastSquares, LinearMap, fasta, proximal
+from . import ExampleProblem, cli_backend, test_modes
 
 __all__ = ["LASSOProblem"]
 
 
 class LASSOProblem(ExampleProblem):
-    def __init__(self, A, b, mu, x=None):
-        self.A, self.b, self.mu, self.x = A, b, mu, x
+    def __init__(self, A, b, mu, x=None, backend="hip"):
+        self.A, self.b, self.mu, self.x, self.backend = A, b, mu, x, backend
 
     def solve(self, x0, fasta_options=None):
-        loss, reg = LeastSquares(self.b), L1Ball(self.mu)
         opts = dict(verbose=False)
         opts.update(fasta_options or {})
-        c = fasta(self.A, loss.f, loss.gradf, reg.g, reg.prox, x0, **opts)
+        if self.backend == "numpy":                 # the reference's closures (lasso.py:42-45), 6-argument call
+            f = lambda z: .5 * la.norm((z - self.b).ravel()) ** 2
+            gradf = lambda z: z - self.b
+            g = lambda x: 0
+            proxg = lambda x, t: proximal.project_L1_ball(x, self.mu)
+            c = fasta(self.A, f, gradf, g, proxg, x0, **opts)
+        else:
+            op = self.A if isinstance(self.A, DenseMatrixMap) else self.device_operator(lambda: DenseMatrixMap(np.asarray(self.A)))
+            loss, reg = LeastSquares(self.b), L1Ball(self.mu)
+            c = fasta(op, loss.f, loss.gradf, reg.g, reg.prox, x0, backend="hip", **opts)
         return c.solution, c
 
     @staticmethod
-    def construct(M=200, N=1000, K=10, sigma=0.01, mu=0.8, seed=None):
+    def construct(M=200, N=1000, K=10, sigma=0.01, mu=0.8, seed=None, backend="hip"):
         if seed is not None:
             np.random.seed(seed)
         x = np.zeros(N)
@@ -31,11 +39,11 @@ class LASSOProblem(ExampleProblem):
         A = np.random.randn(M, N)
         A /= la.norm(A, 2)
         b = A @ x + sigma * np.random.randn(M)
-        return LASSOProblem(LinearMap.from_matrix(A), b, mu, x=x), np.zeros(N)
+        return LASSOProblem(A, b, mu, x=x, backend=backend), np.zeros(N)
 
 
 if __name__ == "__main__":
-    problem, x0 = LASSOProblem.construct()
+    problem, x0 = LASSOProblem.construct(backend=cli_backend())
     print("Constructed LASSO problem.")
     test_modes(problem, x0)
     problem.close()

@@ -4,27 +4,33 @@ Recipe: fasta/examples/sparse_least_squares.py:41-44 (closures), :50-76 (constru
 import numpy as np
 from numpy import linalg as la
 
-from .. import DenseMatrixMap, LeastSquares, Shrink, fasta
-from . import ExampleProblem, test_modes
+from .. import DenseMatrixMap, LeastSquares, Shrink, fasta, proximal
+from . import ExampleProblem, cli_backend, test_modes
 
 __all__ = ["SparseLeastSquaresProblem"]
 
 
 class SparseLeastSquaresProblem(ExampleProblem):
-    def __init__(self, A, At, b, mu, x=None):
-        self.A = A if isinstance(A, DenseMatrixMap) else DenseMatrixMap(np.asarray(A))
-        self.At = self.A.H
-        self.b, self.mu, self.x = b, mu, x
+    def __init__(self, A, At, b, mu, x=None, backend="hip"):
+        self.A, self.At, self.b, self.mu, self.x, self.backend = A, At, b, mu, x, backend
 
     def solve(self, x0, fasta_options=None):
-        loss, reg = LeastSquares(self.b), Shrink(self.mu)
         opts = dict(verbose=False)
         opts.update(fasta_options or {})
-        c = fasta(self.A, self.At, loss.f, loss.gradf, reg.g, reg.prox, x0, **opts)
+        if self.backend == "numpy":                 # the reference's closures (sparse_least_squares.py:41-44)
+            f = lambda z: .5 * la.norm((z - self.b).ravel()) ** 2
+            gradf = lambda z: z - self.b
+            g = lambda x: self.mu * la.norm(x.ravel(), 1)
+            proxg = lambda x, t: proximal.shrink(x, t * self.mu)
+            c = fasta(self.A, self.At, f, gradf, g, proxg, x0, **opts)
+        else:
+            op = self.A if isinstance(self.A, DenseMatrixMap) else self.device_operator(lambda: DenseMatrixMap(np.asarray(self.A)))
+            loss, reg = LeastSquares(self.b), Shrink(self.mu)
+            c = fasta(op, op.H, loss.f, loss.gradf, reg.g, reg.prox, x0, backend="hip", **opts)
         return c.solution, c
 
     @staticmethod
-    def construct(M=200, N=1000, K=10, sigma=0.01, mu=0.02, seed=None):
+    def construct(M=200, N=1000, K=10, sigma=0.01, mu=0.02, seed=None, backend="hip"):
         if seed is not None:
             np.random.seed(seed)
         x = np.zeros(N)
@@ -32,11 +38,11 @@ class SparseLeastSquaresProblem(ExampleProblem):
         A = np.random.randn(M, N)
         A /= la.norm(A, 2)
         b = A @ x + sigma * np.random.randn(M)
-        return SparseLeastSquaresProblem(A, A.T, b, mu, x=x), np.zeros(N)
+        return SparseLeastSquaresProblem(A, A.T, b, mu, x=x, backend=backend), np.zeros(N)
 
 
 if __name__ == "__main__":
-    problem, x0 = SparseLeastSquaresProblem.construct()
+    problem, x0 = SparseLeastSquaresProblem.construct(backend=cli_backend())
     print("Constructed sparse least squares problem.")
     adaptive, accelerated, plain = test_modes(problem, x0)
     print("recovery error ||x - x_true||_inf = {:.3e}".format(np.abs(adaptive[0] - problem.x).max()))

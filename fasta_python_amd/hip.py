@@ -59,6 +59,7 @@ SIGNATURES = {
     "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
     "fh_comm_unique_id": (_i32, [C.c_void_p]),
     "fh_comm_init": (_i32, [_ctx, _i32, _i32, C.c_void_p]),
+    "fh_comm_count": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_comm_destroy": (_i32, [_ctx]),
     "fh_timing_enable": (_i32, [_ctx, _i32]),
     "fh_timing_get": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
@@ -263,6 +264,12 @@ class HipContext:
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._call("fh_comm_init", int(nranks), int(rank), buf)
         self.sharded = True
+
+    def comm_count(self):
+        """Ranks in the attached communicator as RCCL reports them (1 without one)."""
+        n = _i32(0)
+        self._call("fh_comm_count", C.byref(n))
+        return int(n.value)
 
     def comm_destroy(self):
         self._call("fh_comm_destroy")

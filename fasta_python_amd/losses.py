@@ -24,14 +24,13 @@ class LeastSquares:
         """f1 from the device scalar sum (z-b)^2: .5*la.norm(z-b)**2 (sparse_least_squares.py:41)."""
         return .5 * np.float64(math.sqrt(s)) ** 2          # (math.sqrt: same IEEE result, a fraction of np.sqrt's call cost)
 
-    # The device loop evaluates f inside K-fwd/K-adj; these host forms exist so the object can be
-    # inspected or handed to other code.  They are never called by fasta().
+    # The device loop evaluates f inside its kernels and never calls these.  On host arrays they are the reference's
+    # closures (sparse_least_squares.py:41-42), bit for bit, so the generic host loop -- or the reference -- can use them.
     def f(self, z):
-        r = np.asarray(z, dtype=np.float64) - self.b
-        return .5 * float(np.vdot(r, r))
+        return .5 * np.linalg.norm((z - self.b).ravel()) ** 2
 
     def gradf(self, z):
-        return np.asarray(z, dtype=np.float64) - self.b
+        return z - self.b
 
     __call__ = f
 
@@ -51,10 +50,9 @@ class LogisticLoss:
         return np.float64(s)
 
     def f(self, z):
-        z = np.asarray(z, dtype=np.float64)
-        return float(np.sum(np.log(1 + np.exp(z)) - (self.b == 1) * z))
+        return np.sum(np.log(1 + np.exp(z)) - (self.b == 1) * z)
 
     def gradf(self, z):
-        return -self.b / (1 + np.exp(self.b * np.asarray(z, dtype=np.float64)))
+        return -self.b / (1 + np.exp(self.b * z))
 
     __call__ = f

@@ -11,7 +11,13 @@ per backtrack, and reads back ~8 float64 scalars from each to take the reference
 (backtracking test :200, restart test :231, Barzilai-Borwein rule :253-270, stop rule :308).
 Iterates, gradients and residual vectors never leave HBM unless `record_iterates` / `func` ask.
 
-There is NO CPU fallback: operands that are not device-recognised raise TypeError (see `_recognise`).
+Which loop runs is decided by the operand TYPES alone (`_recognise`), never by whether a GPU happens to be there:
+  * device-recognisable operands (matrix / DenseMatrixMap / GradDivMap + tagged loss + tagged prox) run the HIP loop
+    below and RAISE when libfasta_hip.so or the GPU is missing -- there is no CPU fallback for them;
+  * anything else -- Python closures, a callable pair, `A=None`, a host LinearMap: the forms the reference's own
+    examples pass -- cannot execute inside a kernel and runs the generic host loop (generic.py, reference semantics,
+    bit-identical to the reference on the same NumPy);
+  * `backend="hip"` insists on the device loop (TypeError for unrecognisable operands), `backend="numpy"` on the host one.
 """
 
 import math
@@ -62,31 +68,33 @@ def _tag_of(obj, cls):
     return owner if isinstance(owner, cls) else None
 
 
+def _unrecognised(A, At, f, gradf, g, proxg):
+    """None when the seven operands can run on the device, else the reason they cannot (a sentence)."""
+    if not isinstance(A, (np.ndarray, _DeviceMap)):
+        return ("operator A is not device-resident (pass a 2-D float64 ndarray, a linalg.DenseMatrixMap / "
+                "LinearMap.from_matrix(A), or a linalg.GradDivMap); arbitrary Python callables cannot run inside the fused HIP kernels")
+    loss_f, loss_g = _tag_of(f, (LeastSquares, LogisticLoss)), _tag_of(gradf, (LeastSquares, LogisticLoss))
+    if loss_f is None or loss_f is not loss_g:
+        return "f and gradf must be the `.f` / `.gradf` of one losses.LeastSquares(b) or losses.LogisticLoss(b) object"
+    if g is None and proxg is None:
+        return None
+    prox, owner_g = _tag_of(proxg, ProxTag), _tag_of(g, ProxTag)
+    if prox is None or (owner_g is not None and owner_g is not prox) or (owner_g is None and g is not None):
+        return ("g and proxg must be the `.g` / `.prox` of one proximal.* tag object "
+                "(Shrink, NonNeg, LinfProx, L1Ball, Box, TVDualBall)")
+    return None
+
+
 def _recognise(A, At, f, gradf, g, proxg, x0):
-    """Map the reference's seven operands onto device objects, or fail loudly."""
+    """Map the reference's seven operands onto device objects (call only when `_unrecognised` returned None)."""
     if isinstance(A, np.ndarray):
         if A.ndim != 2:
             raise AssertionError("matrix operator must be 2-D")            # linalg.py:40
         if isinstance(At, np.ndarray) and At.shape != A.shape[::-1]:
             raise AssertionError("At must have the transposed shape of A")
         A = DenseMatrixMap(A)
-    if not isinstance(A, _DeviceMap):
-        raise TypeError(
-            "fasta(): operator A is not device-resident.  Pass a 2-D float64 ndarray, a "
-            "linalg.DenseMatrixMap / LinearMap.from_matrix(A), or a linalg.GradDivMap.  Arbitrary Python "
-            "callables cannot run inside the fused HIP kernels and this build has no CPU fallback.")
-    loss_f, loss_g = _tag_of(f, (LeastSquares, LogisticLoss)), _tag_of(gradf, (LeastSquares, LogisticLoss))
-    if loss_f is None or loss_f is not loss_g:
-        raise TypeError("fasta(): f and gradf must be the `.f` / `.gradf` of one losses.LeastSquares(b) or "
-                        "losses.LogisticLoss(b) object")
-    if g is None and proxg is None:
-        prox = NoProx()                                                    # :88-90
-    else:
-        prox = _tag_of(proxg, ProxTag)
-        owner_g = _tag_of(g, ProxTag)
-        if prox is None or (owner_g is not None and owner_g is not prox):
-            raise TypeError("fasta(): g and proxg must be the `.g` / `.prox` of one proximal.* tag object "
-                            "(Shrink, NonNeg, LinfProx, L1Ball, Box, TVDualBall)")
+    loss_f = _tag_of(f, (LeastSquares, LogisticLoss))
+    prox = NoProx() if (g is None and proxg is None) else _tag_of(proxg, ProxTag)      # :88-90
     if tuple(x0.shape) != A.Vshape:
         raise AssertionError(f"x0 has shape {x0.shape}, operator expects {A.Vshape}")   # linalg.py:58
     if loss_f.b.shape != A.Wshape:
@@ -335,9 +343,13 @@ class FBSolver:
                            self.i, solution, self.objectives, self.iterates, self.function_hist)
 
 
-def fasta(A, *operands, **options):
-    """Run FASTA on the MI355X.  Same positional forms, keyword options and defaults as the reference
-    (fasta/__init__.py:38-53); returns `Convergence`.  Build-only keyword: fused="auto"|True|False (see FBSolver)."""
+def fasta(A, *operands, backend="auto", **options):
+    """Run FASTA.  Same positional forms, keyword options and defaults as the reference (fasta/__init__.py:38-53);
+    returns `Convergence`.  Build-only keywords:
+      backend = "auto"  -- device loop for device-recognisable operands (raises if the GPU path is unavailable), generic
+                           host loop for operands that cannot run in a kernel (closures, callable pair, None, host LinearMap);
+                "hip"   -- device loop or TypeError;   "numpy" -- generic host loop (operands are called as given);
+      fused   = "auto" | True | False -- one-pass kernel policy of the device loop (see FBSolver)."""
     if len(operands) == 6:
         At, f, gradf, g, proxg, x0 = operands
     elif len(operands) == 5:
@@ -345,6 +357,16 @@ def fasta(A, *operands, **options):
         f, gradf, g, proxg, x0 = operands
     else:
         raise TypeError("fasta() takes (A, f, gradf, g, proxg, x0) or (A, At, f, gradf, g, proxg, x0)")
+    if backend not in ("auto", "hip", "numpy"):
+        raise ValueError('backend must be "auto", "hip" or "numpy"')
+    why_not = "backend='numpy' was requested" if backend == "numpy" else _unrecognised(A, At, f, gradf, g, proxg)
+    if why_not is not None:
+        if backend == "hip":
+            raise TypeError("fasta(backend='hip'): " + why_not)
+        from .generic import HostFBS, host_map
+        options.pop("fused", None)                                      # device-loop policy, meaningless on the host
+        x0 = np.asarray(x0)
+        return HostFBS(host_map(A, At, x0), f, gradf, g, proxg, x0, **options).setup().run()
     x0 = np.asarray(x0, dtype=np.float64)
     owns = isinstance(A, np.ndarray)
     A, loss, prox = _recognise(A, At, f, gradf, g, proxg, x0)

@@ -164,13 +164,16 @@ int fh_apply(fh_ctx* ctx, int adjoint, const double* in, double* out);
 /* writes an ncclUniqueId (128 bytes) -- rank 0 calls it and ships the bytes to the other ranks     */
 int fh_comm_unique_id(void* id128);
 int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
+/* ranks of the attached communicator as RCCL reports them (ncclCommCount); 1 without a communicator */
+int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
 
 /* ---- measurement: HIP-event timing of each launch on the context's stream --------------------- */
 int fh_timing_enable(fh_ctx* ctx, int on);
 int fh_timing_get(fh_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
 int fh_timing_reset(fh_ctx* ctx);
-/* streaming-read ceiling: reads the device copy of A once with 16-byte loads, returns ms       */
+/* streaming-read ceiling: one read-only pass over the device copy of A in the product's own launch shape (groups of
+ * 8 rows, <= 2 persistent workgroups per CU, non-temporal 16-byte loads, 16 loads in flight per lane), returns ms   */
 int fh_stream_read_ms(fh_ctx* ctx, int reps, double* ms_per_pass, uint64_t* bytes_per_pass);
 
 #ifdef __cplusplus

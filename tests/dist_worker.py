@@ -1,7 +1,13 @@
-"""Worker for tests/test_sharded_cpu.py: one of WORLD_SIZE gloo ranks.  Exercises (1) bench.py's
-rendezvous plumbing (unique-id style byte broadcast, barrier, max-over-ranks) and (2) the row-sharding
-scheme the HIP path implements -- local forward rows, all-reduced ||r||^2, all-reduced A_k^T r_k -- restated
-on the NumPy oracle so it can run without a GPU."""
+"""Worker for tests/test_sharded_cpu.py: one of WORLD_SIZE gloo ranks.  Exercises (1) bench.py's rendezvous plumbing
+(unique-id style byte broadcast, barrier, max-over-ranks) and (2) the PRODUCT under row sharding, two ways:
+
+  path "driver"   fasta_python_amd.FBSolver -- the host driver of the device loop -- over a NumPy stand-in for a row-sharded
+                  device context (tests/fake_ctx.py with this rank's row block; the loss sum and the A_k^T r_k partials are
+                  all-reduced over gloo exactly where fasta_hip.hip calls ncclAllReduce);
+  path "generic"  fasta_python_amd.fasta's generic host loop with sharded closures (local forward rows, all-reduced adjoint).
+
+Every rank must take the same branches and end with the same replicated iterate; the parent test compares rank 0 with a
+single-process run."""
 import os
 import sys
 import warnings
@@ -12,12 +18,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import bench                                    # noqa: E402  (Group = the product's rendezvous helper)
-from oracle import fasta_np as fo               # noqa: E402
-from oracle import problems as pr               # noqa: E402
+import fasta_python_amd as fa                   # noqa: E402
+from fasta_python_amd.linalg import LinearMap, _DeviceMap   # noqa: E402
+from tests.fake_ctx import FakeContext          # noqa: E402
+
+
+def problem(seed, M=96, N=160, K=6, sigma=0.01, mu=0.02):
+    """examples/sparse_least_squares.py:62-74 recipe (same draws as oracle.problems.sparse_least_squares)."""
+    np.random.seed(seed)
+    x = np.zeros(N)
+    x[np.random.permutation(N)[:K]] = 1
+    A = np.random.randn(M, N)
+    A /= np.linalg.norm(A, 2)
+    b = A @ x + sigma * np.random.randn(M)
+    return A, b, mu
+
+
+class ShardedFakeContext(FakeContext):
+    """Row block of A on this rank; sums that fasta_hip.hip all-reduces with RCCL are all-reduced here with gloo."""
+    sharded = True
+
+    def __init__(self, Ak, allreduce):
+        self.allreduce = allreduce
+        FakeContext.__init__(self, lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (Ak.shape[1],), (Ak.shape[0],))
+
+    def _f_sum(self, z):                        # fh_fwd: reduce_fsq_over_ranks; fh_adj: the 1-double all-reduce next to g1
+        return float(self.allreduce(np.array([FakeContext._f_sum(self, z)]))[0])
+
+
+class ShardedFakeMap(_DeviceMap):
+    def __init__(self, Ak, allreduce):
+        self.shape = Ak.shape
+        self.ctx = ShardedFakeContext(Ak, allreduce)
+        LinearMap.__init__(self, self.ctx.fwd_op, self.ctx.adj_op, (Ak.shape[1],), (Ak.shape[0],))
 
 
 def main():
-    out_dir, mode = sys.argv[1], sys.argv[2]
+    out_dir, mode, path = sys.argv[1], sys.argv[2], sys.argv[3]
     grp = bench.Group()
     import torch
     dist = grp.dist
@@ -27,10 +64,8 @@ def main():
     assert grp.max(float(grp.rank)) == float(grp.world - 1)
     grp.barrier()
 
-    # ---- sharded FBS on the oracle ----------------------------------------------------------------
-    np.random.seed(5)
-    P = pr.sparse_least_squares(M=96, N=160, K=6)
-    A, b, mu = P.data["A"], P.data["b"], P.data["mu"]
+    # ---- sharded FBS through the product ------------------------------------------------------------
+    A, b, mu = problem(5)
     m = A.shape[0]
     assert m % grp.world == 0
     lo = grp.rank * (m // grp.world)
@@ -42,17 +77,24 @@ def main():
         dist.all_reduce(t)
         return t.numpy().reshape(np.shape(v))
 
-    Ashard = fo.LinearMap(lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (A.shape[1],), (hi - lo,))
-    f = lambda z: .5 * np.sqrt(float(allreduce(np.sum((z - bk) ** 2)))) ** 2
-    gradf = lambda z: z - bk
-    g = lambda x: mu * np.abs(x).sum()
-    proxg = lambda x, t: fo.shrink(x, t * mu)
-    opts = dict(tolerance=1e-6, evaluate_objective=True, record_iterates=True,
+    opts = dict(tolerance=1e-6, evaluate_objective=True, record_iterates=True, verbose=False,
                 adaptive=(mode != "accelerated"), accelerate=(mode == "accelerated"))
+    x0 = np.zeros(A.shape[1])
     np.random.seed(9)                                   # same Lipschitz probes on every rank
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        c = fo.fasta(Ashard, f, gradf, g, proxg, P.x0, **opts)
+        if path == "driver":
+            op = ShardedFakeMap(Ak, allreduce)
+            ls, reg = fa.LeastSquares(bk), fa.Shrink(mu)
+            c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, x0, **opts)
+            assert op.ctx.calls["fwd"] + op.ctx.calls["pair"] > 0
+        else:
+            Ashard = fa.LinearMap(lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (A.shape[1],), (hi - lo,))
+            f = lambda z: .5 * np.sqrt(float(allreduce(np.sum((z - bk) ** 2)))) ** 2
+            gradf = lambda z: z - bk
+            g = lambda x: mu * np.abs(x).sum()
+            proxg = lambda x, t: fa.proximal.shrink(x, t * mu)
+            c = fa.fasta(Ashard, f, gradf, g, proxg, x0, **opts)
     np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), residuals=c.residuals, stepsizes=c.stepsizes,
              objectives=c.objectives, iterates=c.iterates, solution=c.solution,
              iteration_count=c.iteration_count, backtracks=c.backtracks)

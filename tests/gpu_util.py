@@ -40,7 +40,7 @@ def run_hip(kind, data, options, solver_seed, g_none=False):
         np.random.seed(solver_seed)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            return fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, **o)
+            return fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, backend="hip", **o)
     finally:
         A.close()
 

@@ -157,13 +157,13 @@ def test_unrecognised_operands_fail_loudly():
     A = np.eye(4)
     ls, reg = fa.LeastSquares(np.zeros(4)), fa.Shrink(0.1)
     with pytest.raises(TypeError):
-        fa.fasta(lambda x: x, lambda x: x, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(4))
+        fa.fasta(lambda x: x, lambda x: x, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(4), backend="hip")
     with pytest.raises(TypeError):
-        fa.fasta(A, A.T, lambda z: 0.0, lambda z: z, reg.g, reg.prox, np.zeros(4))
+        fa.fasta(A, A.T, lambda z: 0.0, lambda z: z, reg.g, reg.prox, np.zeros(4), backend="hip")
     with pytest.raises(TypeError):
-        fa.fasta(A, A.T, ls.f, ls.gradf, lambda x: 0, lambda x, t: x, np.zeros(4))
+        fa.fasta(A, A.T, ls.f, ls.gradf, lambda x: 0, lambda x, t: x, np.zeros(4), backend="hip")
     with pytest.raises(AssertionError):
-        fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5))
+        fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5), backend="hip")
 
 
 @pytest.mark.parametrize("m,n", [(4096, 4096), (16384, 2048), (3000, 20000), (16384, 16384)])      # 4096^2 and 16384^2
@@ -178,7 +178,7 @@ def test_mid_size_matches_oracle_loop(m, n):
         ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
         opts = dict(tolerance=1e-6, max_iters=40 if m * n > 2 ** 27 else 60, evaluate_objective=True, record_iterates=True)
         np.random.seed(3)
-        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, **opts)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", **opts)
         P = pr.sparse_least_squares_from(A, b, 0.02)
         np.random.seed(3)
         want = fo.fasta(*P.args7(), **opts)
@@ -202,7 +202,7 @@ def test_row_sharded_code_path_with_one_rank_communicator(accelerate):
     try:
         A.ctx.comm_init(1, 0, hip.comm_unique_id())
         np.random.seed(5)
-        got = fa.fasta(A, loss.f, loss.gradf, reg.g, reg.prox, x0, verbose=False, **opts)
+        got = fa.fasta(A, loss.f, loss.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", **opts)
     finally:
         A.close()
     assert got.iteration_count == ref.iteration_count and got.backtracks == ref.backtracks
@@ -253,7 +253,7 @@ def test_c2_full_size_first_iterations_match_oracle_loop():
         ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
         opts = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, record_iterates=True)
         np.random.seed(3)
-        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, **opts)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", **opts)
         A = op.host_rows(0, m)                       # 32 GiB host copy, D2H
     finally:
         op.close()
@@ -283,7 +283,7 @@ def test_on_device_spectral_norm_matches_numpy(shape):
         # and it is usable as fasta()'s L / tau0 (no RNG probes, fasta/__init__.py:100)
         b = rng.randn(shape[0])
         ls, reg = fa.LeastSquares(b), fa.Shrink(0.1)
-        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(shape[1]), verbose=False, L=L, tau0=(2 / L) / 10,
+        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(shape[1]), verbose=False, backend="hip", L=L, tau0=(2 / L) / 10,
                      max_iters=30, tolerance=0.0)
         assert c.iteration_count == 30 and np.all(np.isfinite(c.residuals[:30]))
     finally:

@@ -55,17 +55,30 @@ def test_config1_sparse_least_squares_through_examples_package(capsys):
     ("tv_denoising", "TVDenoisingProblem", dict(shape=(64, 80), square=16, seed=5)),
     ("sparse_logistic", "SparseLogisticProblem", dict(M=200, N=300, K=4, mu=8.0, seed=6)),
 ])
-def test_other_examples_run_and_converge(module, cls, kw):
+def test_other_examples_match_their_host_twin(module, cls, kw):
+    """Each example on the device (backend "hip") against the same instance on the generic host loop (backend "numpy":
+    the reference's closures, bit-pinned to the reference by tests/test_generic_cpu.py): identical iteration and backtrack
+    counts, histories rtol 1e-6, solution rtol 1e-5."""
     import importlib
     mod = importlib.import_module("fasta_python_amd.examples." + module)
-    problem, x0 = getattr(mod, cls).construct(**kw)
-    try:
-        sol, c = problem.solve(x0, {"tolerance": 1e-4, "max_iters": 400, "evaluate_objective": True})
-        assert c.iteration_count >= 1 and np.all(np.isfinite(sol))
-        obj = c.objectives[:c.iteration_count + 1]
-        assert obj[-1] <= obj[0]
-    finally:
-        problem.close()
+    opts = {"tolerance": 1e-4, "max_iters": 400, "evaluate_objective": True}
+    runs = {}
+    for backend in ("hip", "numpy"):
+        problem, x0 = getattr(mod, cls).construct(backend=backend, **kw)
+        try:
+            np.random.seed(31)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                runs[backend] = problem.solve(x0, dict(opts))
+        finally:
+            problem.close()
+    (sol, c), (wsol, w) = runs["hip"], runs["numpy"]
+    assert c.iteration_count == w.iteration_count >= 1 and c.backtracks == w.backtracks
+    k = c.iteration_count
+    np.testing.assert_allclose(c.residuals[:k], w.residuals[:k], rtol=1e-6, atol=1e-13)
+    np.testing.assert_allclose(c.objectives[:k + 1], w.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(sol, wsol, rtol=1e-5, atol=1e-9)
+    assert w.objectives[k] <= w.objectives[0]
 
 
 def test_verbose_output_format(capsys):
@@ -75,7 +88,7 @@ def test_verbose_output_format(capsys):
     A = rng.randn(20, 30) / 10
     ls, reg = fa.LeastSquares(rng.randn(20)), fa.Shrink(0.01)
     np.random.seed(0)
-    c = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(30), max_iters=3, tolerance=0.0)
+    c = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(30), backend="hip", max_iters=3, tolerance=0.0)
     out = capsys.readouterr().out.splitlines()
     assert out[0] == "Initializing FASTA..."
     assert out[2] == "Iteration #\tResidual\tStepsize\tAccel. param\tBacktracks\tObjective"

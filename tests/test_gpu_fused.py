@@ -143,8 +143,8 @@ def test_unsupported_shape_reports_and_auto_falls_back():
         assert not op.ctx.fused_supported()
         ls, reg = fa.LeastSquares(np.ones(3)), fa.Shrink(0.1)
         with pytest.raises(ValueError):
-            fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=True, max_iters=2)
-        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, max_iters=2, tolerance=0.0)
+            fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", fused=True, max_iters=2)
+        c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", max_iters=2, tolerance=0.0)
         assert c.iteration_count == 2
     finally:
         op.close()
@@ -174,7 +174,7 @@ def test_full_solve_with_fused_steps_matches_oracle(kind):
         np.random.seed(3)
         got = solver.setup().run()
         np.random.seed(3)
-        two = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=False, **opts)
+        two = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", fused=False, **opts)
     finally:
         op.close()
     np.random.seed(3)
@@ -212,7 +212,7 @@ def test_fused_step_on_the_row_sharded_path_with_one_rank(accelerate):
     op = fa.DenseMatrixMap(A)
     try:
         np.random.seed(1)
-        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=True, **opts)
+        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", fused=True, **opts)
         op.ctx.comm_init(1, 0, hip.comm_unique_id())
         solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, fused=True, **opts)
         np.random.seed(1)
@@ -242,7 +242,7 @@ def test_lost_partial_times_out_instead_of_hanging_and_the_solver_falls_back():
     op = fa.DenseMatrixMap(A)
     try:
         np.random.seed(4)
-        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, fused=False, **opts)
+        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", fused=False, **opts)
         op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8 | 64)       # bit 8: the 8-member shape (n = 4096 runs without any exchange by default)
         c = _state(op, b, 0.02, np.zeros(n))
         t0 = time.time()

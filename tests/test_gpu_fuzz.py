@@ -21,7 +21,7 @@ def _pair(A, b, kind, mu, x0, opts, seed):
         reg, P = fa.L1Ball(mu), pr.l1_ball_lasso_from(A, b, mu)
     ls = fa.LeastSquares(b)
     np.random.seed(seed)
-    got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, **opts)
+    got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", **opts)
     np.random.seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -90,7 +90,7 @@ def test_custom_stop_rule_and_matrix_valued_iterate_shapes():
     try:
         ls, reg = fa.LeastSquares(P.data["M"] / P.data["mu"]), fa.TVDualBall()
         np.random.seed(4)
-        c = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, stop_rule=rule, tolerance=0.5)
+        c = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, backend="hip", stop_rule=rule, tolerance=0.5)
     finally:
         op.close()
     assert c.iteration_count == 3 and [a[0] for a in calls] == [0, 1, 2] and calls[0][4] == 0.5

@@ -18,21 +18,29 @@ pytestmark = pytest.mark.gpu
 def test_prox_functions_match_reference_known_answers(golden_dir):
     k = np.load(os.path.join(golden_dir, "kat_prox.npz"))
     x, xr = k["x"], k["xr"]
+    """The DEVICE prox kernels (through proximal.device_prox / tag.prox_on_device) against the reference's known answers."""
+    dev = proximal.device_prox
+    shrink1, linf1, l1ball = fa.Shrink(1.0), fa.LinfProx(1.0), (lambda t: fa.L1Ball(t))
     # elementwise prox: bit-exact (same IEEE operations in the same order)
-    assert np.array_equal(proximal.shrink(x, 1.0), k["shrink_t1"])
-    assert np.array_equal(np.signbit(proximal.shrink(x, 1.0)), np.signbit(k["shrink_t1"]))   # the -0.0 of P1
-    assert np.array_equal(proximal.shrink(xr, 0.3), k["shrink_r"])
-    assert np.array_equal(fa.NonNeg().prox(xr, 0.5), np.maximum(xr, 0))
-    assert np.array_equal(fa.Box(-0.25, 0.5).prox(xr, 0.5), np.clip(xr, -0.25, 0.5))
+    assert np.array_equal(dev(shrink1, x, 1.0), k["shrink_t1"])
+    assert np.array_equal(np.signbit(dev(shrink1, x, 1.0)), np.signbit(k["shrink_t1"]))   # the -0.0 of P1
+    assert np.array_equal(dev(shrink1, xr, 0.3), k["shrink_r"])
+    assert np.array_equal(fa.NonNeg().prox_on_device(xr, 0.5), np.maximum(xr, 0))
+    assert np.array_equal(fa.Box(-0.25, 0.5).prox_on_device(xr, 0.5), np.clip(xr, -0.25, 0.5))
     # level search replaces the sort: equal up to the rounding of the sums
     for t, key in ((1.0, "linf_t1"), (4.0, "linf_t4"), (10.5, "linf_t10p5"), (11.0, "linf_t11")):
-        np.testing.assert_allclose(proximal.project_Linf_ball(x, t), k[key], rtol=0, atol=1e-14, err_msg=key)
+        np.testing.assert_allclose(dev(linf1, x, t), k[key], rtol=0, atol=1e-14, err_msg=key)
     for t, key in ((4.0, "l1_t4"), (1.0, "l1_t1"), (10.5, "l1_t10p5")):
-        np.testing.assert_allclose(proximal.project_L1_ball(x, t), k[key], rtol=0, atol=1e-14, err_msg=key)
-    np.testing.assert_allclose(proximal.project_Linf_ball(xr, 7.0), k["linf_r"], rtol=0, atol=1e-14)
-    np.testing.assert_allclose(proximal.project_L1_ball(xr, 7.0), k["l1_r"], rtol=0, atol=1e-14)
-    with pytest.raises(NotImplementedError):
-        proximal.project_Lnuc_ball(np.eye(3), 1.0)
+        np.testing.assert_allclose(dev(l1ball(t), x, 1.0), k[key], rtol=0, atol=1e-14, err_msg=key)
+    np.testing.assert_allclose(dev(linf1, xr, 7.0), k["linf_r"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(dev(l1ball(7.0), xr, 1.0), k["l1_r"], rtol=0, atol=1e-14)
+    # the scratch context is cached per shape: a second shape, then the first again, and the host forms agree with the device
+    assert len(proximal._scratch) == 2
+    assert np.array_equal(dev(shrink1, x, 1.0), proximal.shrink(x, 1.0))
+    assert np.array_equal(dev(shrink1, xr, 0.3), proximal.shrink(xr, 0.3))
+    assert len(proximal._scratch) == 2
+    proximal.release_scratch()
+    assert not proximal._scratch
 
 
 @pytest.mark.parametrize("n", [1, 2, 63, 1024, 1025, 5000, 20000, 70001])
@@ -42,8 +50,8 @@ def test_level_search_equals_sort_based_level(n):
     for t in (1e-3, 0.7 * np.abs(x).sum(), 0.999 * np.abs(x).sum(), 2.0 * np.abs(x).sum()):
         # the level is a quotient of n-term sums: allow n * ulp(level) of absolute slack on the outputs
         atol = 4e-16 * n * max(1.0, np.abs(x).max())
-        np.testing.assert_allclose(proximal.project_Linf_ball(x, t), fo.prox_linf(x, t), rtol=1e-12, atol=atol)
-        np.testing.assert_allclose(proximal.project_L1_ball(x, t), fo.project_l1(x, t), rtol=1e-12, atol=atol)
+        np.testing.assert_allclose(proximal.device_prox(fa.LinfProx(1.0), x, t), fo.prox_linf(x, t), rtol=1e-12, atol=atol)
+        np.testing.assert_allclose(proximal.device_prox(fa.L1Ball(t), x, 1.0), fo.project_l1(x, t), rtol=1e-12, atol=atol)
 
 
 TV_SHAPES = [(1, 1), (1, 5), (5, 1), (2, 2), (16, 128), (17, 129), (33, 300), (40, 257), (96, 96)]
@@ -65,7 +73,8 @@ def test_stencil_pair_matches_numpy_rolls(H_, W_):
 def test_tv_ball_prox_is_bit_exact():
     rng = np.random.RandomState(4)
     Y = rng.randn(37, 45, 2) * 1.5
-    assert np.array_equal(fa.TVDualBall().prox(Y, 0.3), fo.tv_dual_ball(Y))
+    assert np.array_equal(fa.TVDualBall().prox_on_device(Y, 0.3), fo.tv_dual_ball(Y))
+    assert np.array_equal(fa.TVDualBall().prox(Y, 0.3), fo.tv_dual_ball(Y))        # the host form, same bits
 
 
 @pytest.mark.parametrize("name", ["tv_32x32_accelerated", "tv_32x32_plain", "l1ball_64x128_adaptive",
@@ -103,7 +112,7 @@ def test_tv_denoising_recovers_piecewise_constant_image():
         ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
         opts = dict(max_iters=60, tolerance=1e-4, evaluate_objective=True)
         np.random.seed(2)
-        got = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, **opts)
+        got = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, backend="hip", **opts)
         np.random.seed(2)
         want = fo.fasta(*P.args7(), **opts)
         assert got.iteration_count == want.iteration_count and got.backtracks == want.backtracks
@@ -180,7 +189,7 @@ def test_tv_solve_identical_with_and_without_the_one_pass_kernel():
         out = []
         for fused in (True, False):
             np.random.seed(2)
-            out.append(fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, fused=fused, **opts))
+            out.append(fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, backend="hip", fused=fused, **opts))
     finally:
         op.close()
     a, b = out

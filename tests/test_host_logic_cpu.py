@@ -83,12 +83,15 @@ def test_operand_recognition_errors_without_a_gpu():
     A = FakeDenseMap(np.eye(4))
     ls, reg = fa.LeastSquares(np.zeros(4)), fa.Shrink(0.1)
     other = fa.Shrink(0.2)
+    # backend="hip" insists on the device loop: operands it cannot take are a TypeError, not a detour over the host
     with pytest.raises(TypeError):
-        fa.fasta(A, lambda z: 0.0, ls.gradf, reg.g, reg.prox, np.zeros(4), verbose=False)
+        fa.fasta(A, lambda z: 0.0, ls.gradf, reg.g, reg.prox, np.zeros(4), verbose=False, backend="hip")
     with pytest.raises(TypeError):
-        fa.fasta(A, ls.f, ls.gradf, other.g, reg.prox, np.zeros(4), verbose=False)      # g and proxg from different tags
+        fa.fasta(A, ls.f, ls.gradf, other.g, reg.prox, np.zeros(4), verbose=False, backend="hip")      # g and proxg from different tags
     with pytest.raises(TypeError):
-        fa.fasta(A, ls.f, fa.LeastSquares(np.zeros(4)).gradf, reg.g, reg.prox, np.zeros(4), verbose=False)
+        fa.fasta(A, ls.f, fa.LeastSquares(np.zeros(4)).gradf, reg.g, reg.prox, np.zeros(4), verbose=False, backend="hip")
+    with pytest.raises(TypeError):
+        fa.fasta(lambda x: x, lambda x: x, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(4), verbose=False, backend="hip")
     with pytest.raises(AssertionError):
         fa.fasta(A, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(5), verbose=False)
     with pytest.raises(TypeError):

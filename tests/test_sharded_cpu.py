@@ -1,5 +1,8 @@
-"""world_size-2 gloo test of the N>1 path on CPU: rendezvous plumbing of bench.py and the row-sharding
-arithmetic (one all-reduce of the A^T partial sums per iteration, all-reduced ||r||^2 for the line search)."""
+"""world_size-2 gloo tests of the N>1 path on CPU: bench.py launching its own workers, its rendezvous plumbing, and the
+PRODUCT under row sharding -- the device loop's host driver (FBSolver) over a sharded NumPy stand-in for the device
+context, and the generic host loop with sharded closures (one all-reduce of the A^T partial sums per iteration,
+all-reduced ||r||^2 for the line search)."""
+import json
 import os
 import socket
 import subprocess
@@ -23,11 +26,12 @@ def _free_port():
     return port
 
 
+@pytest.mark.parametrize("path", ["driver", "generic"])
 @pytest.mark.parametrize("mode", ["adaptive", "accelerated"])
-def test_two_rank_row_sharding_matches_single_rank(tmp_path, mode):
+def test_two_rank_row_sharding_matches_single_rank(tmp_path, mode, path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode]
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode, path]
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
@@ -50,6 +54,27 @@ def test_two_rank_row_sharding_matches_single_rank(tmp_path, mode):
     np.testing.assert_allclose(r0["residuals"][:k], want.residuals[:k], rtol=1e-8)
     np.testing.assert_allclose(r0["objectives"][:k + 1], want.objectives[:k + 1], rtol=1e-10)
     np.testing.assert_allclose(r0["iterates"][:k + 1], want.iterates[:k + 1], rtol=1e-8, atol=1e-12)
+
+
+def test_bench_starts_its_own_workers_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment: the script must launch its two workers itself
+    (as a child process) and relay rank 0's single JSON line on stdout.  --plumbing-only keeps the GPU out of it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # exactly one line on stdout, and it is JSON
+    out = json.loads(lines[0])
+    assert out["ranks"] == 2 and out["n_gpus"] == 2 and out["rows_per_rank"] == 32768
+    assert out["max_elapsed_s"] >= 0.02                 # the slower rank's time (max over ranks)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr
 
 
 def test_row_partition_of_bench_covers_matrix_once():
