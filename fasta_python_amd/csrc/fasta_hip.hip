@@ -1269,21 +1269,21 @@ extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint6
   FH_TRY(check_ready(c, false));
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "stream-read ceiling needs a dense matrix");
   if (reps < 1) reps = 1;
-  // same launch shape as K-fwd at this size: groups of 8 rows, <= 2 persistent workgroups per CU, non-temporal 16-byte loads
-  const uint32_t ld2 = (uint32_t)(c->ld / 2), nrg = (uint32_t)(c->mp / 8);
-  const unsigned grid = (unsigned)std::min<long long>(std::max<uint32_t>(nrg, 1u), c->fwd_cap > 0 ? c->fwd_cap : 512);
+  // persistent workgroups, 1 per CU by default (FH_TUNE_FWD_GRID_CAP overrides), two register buffers of 16 nt loads per lane
+  const uint64_t npieces = c->mp * (c->ld / 2);
+  const unsigned grid = (unsigned)(c->fwd_cap > 0 ? c->fwd_cap : (c->ncu > 0 ? c->ncu : 256));
   double* sink = c->dscal + FH_NSCALARS + 2;
-  k_stream_probe<8, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, ld2, nrg, sink);   // warm-up
+  k_stream_probe<16, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, npieces, sink);   // warm-up
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; ++i) k_stream_probe<8, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, ld2, nrg, sink);
+  for (int i = 0; i < reps; ++i) k_stream_probe<16, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, npieces, sink);
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (ms_per_pass) *ms_per_pass = ms / reps;
-  if (bytes_per_pass) *bytes_per_pass = (uint64_t)nrg * 8 * ld2 * 16;
+  if (bytes_per_pass) *bytes_per_pass = npieces * 16;
   return 0;
 }

@@ -442,34 +442,41 @@ __global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len,
   }
 }
 
-// Read-only streaming pass over A, the "achievable ceiling" printed next to the 8 TB/s spec peak.  It is shaped like
-// the product's own row streams so that it bounds them: persistent workgroups (<= 2 per CU) grid-striding over groups of
-// R whole rows, every lane keeping 2*R non-temporal 16-byte loads in flight, nothing but an add per element -- K-fwd's
-// m-side loop with the x multiply, the prox recompute and every reduction removed.  (Round 1's probe used plain loads
-// from 8192 transient workgroups and topped out below K-fwd itself.)
-template <int R, int NT>
-__global__ __launch_bounds__(FH_WG) void k_stream_probe(const double* A, uint32_t ld2, uint32_t nrg, double* sink) {
-  const uint32_t tid = threadIdx.x;
-  const uint32_t ntrip = (ld2 + 2 * FH_WG - 1) / (2 * FH_WG);
-  double acc[R];
+// Read-only streaming pass over A, the "achievable ceiling" printed next to the 8 TB/s spec peak.  Shaped like the
+// product's fastest stream (the one-pass kernel) so that it bounds the product: persistent workgroups (1-2 per CU), every
+// lane keeps THREE rotating register buffers of U non-temporal 16-byte loads (U = 16: 128-192 KiB in flight per workgroup), the
+// next tile's loads are issued before the current tile is consumed, branch-free clamped addressing so the compiler keeps
+// counted `vmcnt` waits, and nothing but one add per element.  (Round 1's probe -- plain loads from 8192 transient
+// workgroups -- and a K-fwd-shaped loop that drains `vmcnt(0)` every trip both topped out BELOW the product kernels.)
+template <int U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_stream_probe(const double* A, uint64_t npieces, double* sink) {
+  const d2* p = reinterpret_cast<const d2*>(A);
+  const uint64_t tile = (uint64_t)U * FH_WG;                       // 16-byte pieces per workgroup per trip
+  const uint64_t ntiles = (npieces + tile - 1) / tile;
+  const uint64_t last = npieces - 1;
+  d2 b0[U], b1[U], b2[U];
+  double acc = 0.0, acc2 = 0.0;
+  // (the empty asm statements pin the issue order: without them hipcc sinks each load to just behind the add that frees
+  // its register and ends every trip on `vmcnt(0)`, i.e. with nothing in flight)
+  auto load = [&](d2 (&buf)[U], uint64_t t) {                       // tiles past the end re-read the last one (clamped)
+    const uint64_t base = (t < ntiles ? t : ntiles - 1) * tile + threadIdx.x;
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.0;
-  for (uint32_t rg = blockIdx.x; rg < nrg; rg += gridDim.x) {
-    const d2* Ab = reinterpret_cast<const d2*>(A) + (uint64_t)rg * R * ld2;
-    for (uint32_t t = 0; t < ntrip; ++t) {
-      const uint32_t c0 = t * (2 * FH_WG) + tid, c1 = c0 + FH_WG;
-      const uint32_t k0 = c0 < ld2 ? c0 : 0u, k1 = c1 < ld2 ? c1 : 0u;
-      d2 a0[R], a1[R];
+    for (int j = 0; j < U; ++j) { const uint64_t i = base + (uint64_t)j * FH_WG; buf[j] = load_stream<NT>(p + (i < last ? i : last)); }
+    asm volatile("" ::: "memory");
+  };
+  auto eat = [&](const d2 (&buf)[U]) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) a0[r] = load_stream<NT>(Ab + (uint64_t)r * ld2 + k0);
-#pragma unroll
-      for (int r = 0; r < R; ++r) a1[r] = load_stream<NT>(Ab + (uint64_t)r * ld2 + k1);
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] += (a0[r].x + a0[r].y) + (a1[r].x + a1[r].y);
-    }
+    for (int j = 0; j < U; ++j) { acc += buf[j].x; acc2 += buf[j].y; }   // serial chains: the adds cannot be hoisted above the loads of later tiles
+    asm volatile("" ::: "memory");
+  };
+  const uint64_t g = gridDim.x;
+  uint64_t t = blockIdx.x;
+  load(b0, t);
+  load(b1, t + g);
+  for (; t < ntiles; t += 3ull * g) {          // two tiles (2*U loads per lane) stay in flight behind the one being consumed
+    load(b2, t + 2ull * g); eat(b0);
+    load(b0, t + 3ull * g); eat(b1);
+    load(b1, t + 4ull * g); eat(b2);
   }
-  double s = 0.0;
-#pragma unroll
-  for (int r = 0; r < R; ++r) s += acc[r];
-  if (s == 1.2345e300) sink[0] = s;   // never true; keeps the loads alive
+  if (acc + acc2 == 1.2345e300) sink[0] = acc;   // never true; keeps the loads alive
 }
