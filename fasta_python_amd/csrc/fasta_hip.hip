@@ -125,6 +125,15 @@ struct fh_ctx {
   double* ZX[2] = {nullptr, nullptr};   // stencil + FISTA: extrapolated z' (the residual source of the next g0)
   int zxc = 0;
   const double* zcur = nullptr;         // stencil: z at the current x0 (Z[zc], or ZX[zxc] after an accelerated step)
+  // stencil + FISTA in ONE pass (k_fused_tv_accel): the iterate and its image are kept LAZILY as (P1, P0, c) and (Z1, Z0, c):
+  // x0 = P1 + c*(P1 - P0), z(x0) = Z1 + c*(Z1 - Z0) are formed inside the next sweep and never written.  Buffers are taken
+  // from the n-side pool {X[0], X[1], X[2], P[0], P[1]} and the m-side pool {Z[0], Z[1], ZX[0]} by index.
+  bool lazy = false;
+  int lq1 = 0, lq0 = 0, lqn = 0;        // last prox output, the one before, target of the next launch
+  int lz1 = 0, lz0 = 0, lzn = 0;        // their images
+  int lb1 = 0, lb0 = 0;                 // best-quality iterate = nq(lb1) + lbc*(nq(lb1) - nq(lb0)), by reference
+  double lbc = 0.0, lc = 0.0, lc_pending = 0.0;   // coefficient of the best iterate / of x0 / decided by the launch awaiting fh_commit
+  uint64_t commits = 0;                 // fh_commit calls since fh_init
   bool has_b = false;
   int loss_kind = LOSS_LSQ;
   // prox
@@ -482,9 +491,38 @@ static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
   }
 }
 
+// ---- lazily-kept stencil iterate (one-pass FISTA) ---------------------------------------------------
+static inline double* nq(fh_ctx* c, int i) { return i < 3 ? c->X[i] : c->P[i - 3]; }
+static inline double* mq(fh_ctx* c, int i) { return i < 2 ? c->Z[i] : c->ZX[0]; }
+static void lazy_pick_targets(fh_ctx* c) {
+  for (int k = 0; k < 5; ++k) if (k != c->lq1 && k != c->lq0 && k != c->lb1 && k != c->lb0) { c->lqn = k; break; }
+  for (int k = 0; k < 3; ++k) if (k != c->lz1 && k != c->lz0) { c->lzn = k; break; }
+}
+static int not_lazy(fh_ctx* c, const char* what) {
+  if (c->lazy) return fail(FH_E_STATE, "%s: this solve runs the one-pass accelerated stencil step (fh_step_accel), whose iterate is kept "
+                           "in extrapolated-on-the-fly form; call fh_init before switching kernels", what);
+  return 0;
+}
+// device pointer for fh_get_vector while the iterate is lazy: x0 / x1 / best are materialised into scratch T[2]
+static int lazy_vec(fh_ctx* c, int which, double** out) {
+  int a = -1, b = -1; double coef = 0.0;
+  switch (which) {
+    case FH_VEC_X0: case FH_VEC_X1: a = c->lq1; b = c->lq0; coef = c->lc; break;
+    case FH_VEC_BEST: a = c->lb1; b = c->lb0; coef = c->lbc; break;
+    case FH_VEC_XPROX: *out = nq(c, c->lqn); return 0;
+    default: *out = nullptr; return 0;
+  }
+  const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 4096);
+  k_extrapolate_vec<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->T[2], nq(c, a), nq(c, b), coef, c->n);
+  HIP_TRY(hipGetLastError());
+  *out = c->T[2];
+  return 0;
+}
+
 extern "C" int fh_set_vector(fh_ctx* c, int which, const double* host, uint64_t len) {
   if (!c || !host) return fail(FH_E_ARG, "null argument");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  if (which == FH_VEC_X0) c->lazy = false;          // a new start: fh_init follows
   uint64_t want = 0;
   double* d = vec_ptr(c, which, &want);
   if (!d) return fail(FH_E_ARG, "unknown vector id %d", which);
@@ -500,9 +538,11 @@ extern "C" int fh_get_vector(fh_ctx* c, int which, double* host, uint64_t len) {
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
   uint64_t want = 0;
   double* d = vec_ptr(c, which, &want);
+  FH_TRY(use_device(c));
+  if (c->lazy && (which == FH_VEC_X0 || which == FH_VEC_X1 || which == FH_VEC_BEST || which == FH_VEC_XPROX)) FH_TRY(lazy_vec(c, which, &d));
+  if (c->lazy && which == FH_VEC_Z) d = mq(c, c->lzn);
   if (!d) return fail(FH_E_ARG, "unknown vector id %d", which);
   if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
-  FH_TRY(use_device(c));
   HIP_TRY(hipMemcpyAsync(host, d, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return finish(c);
 }
@@ -965,6 +1005,7 @@ static int check_ready(fh_ctx* c, bool need_b) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_init(fh_ctx* c, double* scalars) {
   FH_TRY(check_ready(c, true));
+  c->lazy = false; c->commits = 0;
   double* x0 = c->X[c->xi];
   // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
   bool fused_done = false;
@@ -1024,6 +1065,7 @@ extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
 
 extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
+  FH_TRY(not_lazy(c, "fh_fwd"));
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
@@ -1032,6 +1074,7 @@ extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
 
 extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* scalars) {
   FH_TRY(check_ready(c, true));
+  FH_TRY(not_lazy(c, "fh_adj"));
   AdjIO io;
   io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
   io.mode = 0; io.tau = tau;
@@ -1047,6 +1090,7 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
 // (fasta/__init__.py:181-188 and :248-260 in one call; a rejected step has wasted the K-adj launch).
 extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
+  FH_TRY(not_lazy(c, "fh_fwd_adj"));
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
@@ -1099,10 +1143,38 @@ static int launch_fused_tv(fh_ctx* c, double tau) {
   return 0;
 }
 
+static int launch_fused_tv_accel(fh_ctx* c, double tau, double coef, int restart) {
+  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
+    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
+  TvAccelP p;
+  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
+  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
+  p.strip_groups = ((p.W + TVF_OWN - 1) / TVF_OWN + 3) / 4;
+  p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn);
+  p.z1 = mq(c, c->lz1); p.z0 = mq(c, c->lz0); p.zn = mq(c, c->lzn);
+  p.b = c->b; p.tau = tau; p.cprev = c->lc; p.coef = coef; p.restart = restart;
+  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
+  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
+  t_begin(c, FH_K_FUSED);
+#define TV_ACCEL(U, NT)                                                                                             \
+  do {                                                                                                              \
+    if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_accel<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
+    else k_fused_tv_accel<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
+  } while (0)
+  if (c->tv_nt) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 8) TV_ACCEL(8, 1); else TV_ACCEL(4, 1); }
+  else { if (c->tv_u == 2) TV_ACCEL(2, 0); else if (c->tv_u == 8) TV_ACCEL(8, 0); else TV_ACCEL(4, 0); }
+#undef TV_ACCEL
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // One-pass FBS iteration: K-fwd and K-adj of the same tau from a single read of A (no acceleration).
 // Writes the complete FH_S_* block; scalars[15] != 0 reports a spin timeout (results invalid: use the two-launch path).
 extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
+  FH_TRY(not_lazy(c, "fh_step"));
   if (c->op == OP_STENCIL) {
     if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
     FH_TRY(launch_fused_tv(c, tau));
@@ -1138,7 +1210,23 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
 // travels to the separate n-side epilogue through a device scalar.
 extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, double* scalars) {
   FH_TRY(check_ready(c, true));
-  if (c->op != OP_DENSE) return fail(FH_E_STATE, "fh_step_accel: dense operator only");
+  if (c->op == OP_STENCIL) {
+    if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+    if (!c->lazy) {      // first accelerated one-pass step after fh_init: x0 = X[xi] (c = 0), z(x0) = Z[zc], best = x0
+      if (!c->zcur) return fail(FH_E_STATE, "fh_step_accel on the stencil operator before fh_init");
+      if (c->commits) return fail(FH_E_STATE, "fh_step_accel on the stencil operator must drive the solve from the first iteration after fh_init");
+      c->lazy = true;
+      c->lq1 = c->lq0 = c->lb1 = c->lb0 = c->xi;
+      c->lz1 = c->lz0 = c->zc;
+      c->lc = c->lbc = c->lc_pending = 0.0;
+      lazy_pick_targets(c);
+    }
+    FH_TRY(launch_fused_tv_accel(c, tau, coef, restart ? 1 : 0));
+    c->last_accel = true;
+    FH_TRY(fetch_scalars(c, scalars));
+    c->lc_pending = (restart && c->hscal[FH_S_RDOT] > 1E-30) ? 0.0 : coef;      // what the launch applied (:231); adopted by fh_commit
+    return 0;
+  }
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   const bool sharded = c->comm != nullptr;
   double* g1 = c->G[c->gc ^ 1];
@@ -1168,6 +1256,15 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
 
 extern "C" int fh_commit(fh_ctx* c, int save_best) {
   FH_TRY(check_ready(c, false));
+  c->commits += 1;
+  if (c->lazy) {                                    // rotate the (P1, P0, c) / (Z1, Z0, c) state; nothing is copied
+    c->lq0 = c->lq1; c->lq1 = c->lqn;
+    c->lz0 = c->lz1; c->lz1 = c->lzn;
+    c->lc = c->lc_pending;
+    if (save_best) { c->lb1 = c->lq1; c->lb0 = c->lq0; c->lbc = c->lc; }
+    lazy_pick_targets(c);
+    return 0;
+  }
   if (c->last_accel) {
     c->pc ^= 1;                                   // x_accel0 <- this iteration's prox output (P ping-pong)
   } else {

@@ -615,3 +615,242 @@ __global__ __launch_bounds__(FH_WG) void k_fused_tv_step(const TvStepFwdP p) {
     }
   }
 }
+
+// =================================================================================================
+// ONE-PASS FBS iteration for the stencil pair WITH acceleration (FISTA, fasta/__init__.py:220-248).
+//
+// The extrapolation coefficient of an accelerated step depends on this step's own restart dot
+// <x0 - xprox, xprox - x_accel0> (:231) -- a sum over the whole image that is only complete when the sweep ends,
+// while g1 = grad(z1' - b) and the BB sums need the coefficient pixel by pixel.  Two things make one sweep enough:
+//   * the sweep carries BOTH candidates (c = coef and c = 0, the restart case) through the g1 / BB arithmetic -- a
+//     second residual stream in registers and five more accumulators, no extra memory traffic -- and the finalising
+//     workgroup, which knows the dot, publishes the set the reference's branch would have computed;
+//   * the extrapolated iterate and its image are never written: the state is (last two prox outputs P1, P0, their
+//     images Z1 = div P1, Z0 = div P0, the coefficient c_prev that was applied), and the next sweep forms
+//     x0 = P1 + c_prev (P1 - P0) and z(x0) = Z1 + c_prev (Z1 - Z0) on the fly -- the same IEEE expressions the
+//     reference evaluates at :242-243, so the bits are the ones it would have stored.
+// Per pixel: reads P1 16 + P0 16 + Z1 8 + Z0 8 + b 8 (P0 / Z0 skipped while c_prev = 0), writes xprox 16 + z_new 8
+// = 80 B against 160 B for the two-launch pair (k_fwd_tv_step 56 + k_adj_tv_step 104 with its x1 / z' outputs).
+// Lane / halo layout as k_fused_tv_step.
+// =================================================================================================
+struct TvAccelP {
+  uint32_t H, W, strip_groups, rows_wg;
+  const double* p1; const double* p0;   // (H,W,2): the last two prox outputs; x0 = p1 + cprev*(p1 - p0); x_accel0 of this step = p1
+  double* pn;                            // (H,W,2): this step's prox output
+  const double* z1; const double* z0;   // (H,W): div of p1 / p0; z at x0 = z1 + cprev*(z1 - z0); z_accel0 of this step = z1
+  double* zn;                            // (H,W): div of this step's prox output
+  const double* b;
+  double tau, cprev, coef;
+  int restart;
+  double* red; unsigned* counter; double* out;
+};
+
+template <int IDENT, int TV_U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_fused_tv_accel(const TvAccelP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
+  const uint32_t first = (sg * 4u + wave) * TVF_OWN;
+  const uint32_t cw = (first + lane + 2u * p.W - 2u) % p.W;       // lane L <-> image column first + L - 2 (periodic); lanes 2..62 own
+  const uint32_t c = first + lane - 2u;
+  const bool own = lane >= 2u && lane <= 62u && c < p.W;
+  const bool lag = p.cprev != 0.0;                                 // uniform: the previous step extrapolated
+  double v[5] = {0, 0, 0, 0, 0};                                  // dxg0, dx2, xh2, g02, restart dot
+  double u0[4] = {0, 0, 0, 0};                                    // candidate c = 0   : dxdg, dg2, gsum, gmax  (xh2 = v[2], f = fs)
+  double u1[6] = {0, 0, 0, 0, 0, 0};                              // candidate c = coef: dxdg, dg2, xh2, gsum, gmax, f
+  double fs = 0.0;
+
+  auto row_of = [&](uint32_t base, int off) -> uint32_t {
+    const int64_t Hh = (int64_t)p.H;
+    return (uint32_t)((((int64_t)base + off) % Hh + Hh) % Hh);
+  };
+  auto x0_of = [&](d2 p1v, d2 p0v) -> d2 {                        // :242 of the previous iteration, evaluated now
+    if (!lag) return p1v;
+    d2 x;
+    x.x = extrapolate(p1v.x, p0v.x, p.cprev);
+    x.y = extrapolate(p1v.y, p0v.y, p.cprev);
+    return x;
+  };
+  auto zc_of = [&](double z1v, double z0v) -> double { return lag ? extrapolate(z1v, z0v, p.cprev) : z1v; };   // :243
+  auto resid_at = [&](uint32_t row) -> double {
+    const uint64_t pix = (uint64_t)row * p.W + cw;
+    const double z1v = load_f64<NT>(p.z1 + pix);
+    return sub_nofma(zc_of(z1v, lag ? load_f64<NT>(p.z0 + pix) : 0.0), load_f64<NT>(p.b + pix));
+  };
+  auto prox_pixel = [&](d2 x0v, double r_me, double r_up, double r_left, d2& g0v, d2& xh) -> d2 {
+    g0v.x = sub_nofma(r_up, r_me);
+    g0v.y = sub_nofma(r_left, r_me);
+    xh.x = fwd_point(x0v.x, g0v.x, p.tau);
+    xh.y = fwd_point(x0v.y, g0v.y, p.tau);
+    return IDENT ? xh : tv_ball(xh);
+  };
+
+  // ---- prologue: halo row i0-1 (needs the residual of rows i0-2 and i0-1) ----------------------------------------
+  double rc_up = resid_at(row_of(i0, -2));
+  d2 x0_prev, xh_prev, xp_prev, p1_prev;
+  double b_prev, z1_prev, rn0_prev = 0.0, rn1_prev = 0.0;
+  {
+    const uint64_t pix = (uint64_t)row_of(i0, -1) * p.W + cw;
+    p1_prev = load_stream<NT>(reinterpret_cast<const d2*>(p.p1) + pix);
+    d2 p0v = {0.0, 0.0};
+    if (lag) p0v = load_stream<NT>(reinterpret_cast<const d2*>(p.p0) + pix);
+    x0_prev = x0_of(p1_prev, p0v);
+    b_prev = load_f64<NT>(p.b + pix);
+    z1_prev = load_f64<NT>(p.z1 + pix);
+    const double r_me = sub_nofma(zc_of(z1_prev, lag ? load_f64<NT>(p.z0 + pix) : 0.0), b_prev);
+    const double r_left = __shfl_up(r_me, 1, 64);
+    d2 g0v;
+    xp_prev = prox_pixel(x0_prev, r_me, rc_up, r_left, g0v, xh_prev);
+    rc_up = r_me;
+  }
+  // step t loads row i0+t and finishes z_new / the BB terms of row i0+t-1 (t = 0 finishes the halo row: only its r_new is kept)
+  for (uint32_t t0 = 0; t0 <= rows; t0 += TV_U) {
+    d2 xv1[TV_U], xv0[TV_U];
+    double zv1[TV_U], zv0[TV_U], bv[TV_U];
+    uint64_t npix[TV_U];
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const uint32_t t = min(t0 + q, rows);
+      npix[q] = (uint64_t)row_of(i0, (int)t) * p.W + cw;
+      xv1[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p1) + npix[q]);
+      zv1[q] = load_f64<NT>(p.z1 + npix[q]);
+      bv[q] = load_f64<NT>(p.b + npix[q]);
+      xv0[q] = (d2){0.0, 0.0};
+      zv0[q] = 0.0;
+      if (lag) {
+        xv0[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p0) + npix[q]);
+        zv0[q] = load_f64<NT>(p.z0 + npix[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const uint32_t t = t0 + q;
+      if (t <= rows) {                                             // wave-uniform
+        // ---- new row i0+t: x0, forward point, prox (owned when t < rows) ----
+        const d2 x0v = x0_of(xv1[q], xv0[q]);
+        const double r_n = sub_nofma(zc_of(zv1[q], zv0[q]), bv[q]);
+        const double r_left = __shfl_up(r_n, 1, 64);
+        d2 g0v, xh;
+        const d2 xp = prox_pixel(x0v, r_n, rc_up, r_left, g0v, xh);
+        if (own && t < rows) {
+          store_d2<NT>(reinterpret_cast<d2*>(p.pn) + npix[q], xp);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double dx = sub_nofma(xp[e], x0v[e]);
+            const double dh = sub_nofma(xp[e], xh[e]);
+            v[0] = fma(dx, g0v[e], v[0]);
+            v[1] = fma(dx, dx, v[1]);
+            v[2] = fma(dh, dh, v[2]);
+            v[3] = fma(g0v[e], g0v[e], v[3]);
+            v[4] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], xv1[q][e]), v[4]);      // x_accel0 = P1 (:222, :231)
+          }
+        }
+        // ---- finish row i0+t-1: z_new, both candidates of z1' / r_new / g1 / the BB terms ----
+        const double right_y = __shfl_down(xp_prev.y, 1, 64);
+        double zo;
+        {
+#pragma clang fp contract(off)
+          const double a0 = xp.x - xp_prev.x;
+          const double a1 = right_y - xp_prev.y;
+          zo = a0 + a1;
+        }
+        const double rn0 = sub_nofma(zo, b_prev);
+        const double rn1 = sub_nofma(extrapolate(zo, z1_prev, p.coef), b_prev);          // z_accel0 = Z1 (:224, :243)
+        const double rn0_left = __shfl_up(rn0, 1, 64);
+        const double rn1_left = __shfl_up(rn1, 1, 64);
+        if (own && t >= 1u) {
+          store_f64<NT>(p.zn + (uint64_t)(i0 + t - 1u) * p.W + c, zo);
+          fs = fma(rn0, rn0, fs);
+          u1[5] = fma(rn1, rn1, u1[5]);
+          d2 ga, gb;
+          ga.x = sub_nofma(rn0_prev, rn0);  ga.y = sub_nofma(rn0_left, rn0);
+          gb.x = sub_nofma(rn1_prev, rn1);  gb.y = sub_nofma(rn1_left, rn1);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double dx = sub_nofma(xp_prev[e], x0_prev[e]);
+            const double dga = bb_dgrad(ga[e], xh_prev[e], x0_prev[e], p.tau);
+            const double dgb = bb_dgrad(gb[e], xh_prev[e], x0_prev[e], p.tau);
+            const double x1 = extrapolate(xp_prev[e], p1_prev[e], p.coef);              // :242
+            const double dh = sub_nofma(x1, xh_prev[e]);
+            u0[0] = fma(dx, dga, u0[0]);
+            u0[1] = fma(dga, dga, u0[1]);
+            u0[2] += fabs(xp_prev[e]);
+            u0[3] = fmax(u0[3], fabs(xp_prev[e]));
+            u1[0] = fma(dx, dgb, u1[0]);
+            u1[1] = fma(dgb, dgb, u1[1]);
+            u1[2] = fma(dh, dh, u1[2]);
+            u1[3] += fabs(x1);
+            u1[4] = fmax(u1[4], fabs(x1));
+          }
+        }
+        rn0_prev = rn0; rn1_prev = rn1;
+        x0_prev = x0v; xh_prev = xh; xp_prev = xp; b_prev = bv[q]; p1_prev = xv1[q]; z1_prev = zv1[q]; rc_up = r_n;
+      }
+    }
+  }
+  // partials per workgroup: [0] fs [1..4] v0..v3 [5] rdot [6..8] u0 dxdg, dg2, gsum [9..13] u1 dxdg, dg2, xh2, gsum, f  [14] u0 gmax [15] u1 gmax
+  {
+    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], u0[0], u0[1]};
+    block_reduce<8>(w, s_scr, -1);
+    double w2[6] = {u0[2], u1[0], u1[1], u1[2], u1[3], u1[5]};
+    block_reduce<6>(w2, s_scr, -1);
+    double w3[2] = {u0[3], u1[4]};
+    { const double m0 = wave_max(w3[0]), m1 = wave_max(w3[1]); if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; } }
+    __syncthreads();
+    if (tid == 0) {
+      double* slot = p.red + (uint64_t)blockIdx.x * 16;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) store_partial(slot + k, w[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) store_partial(slot + 8 + k, w2[k]);
+      store_partial(slot + 14, fmax(fmax(s_scr[0], s_scr[2]), fmax(s_scr[4], s_scr[6])));
+      store_partial(slot + 15, fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7])));
+    }
+  }
+  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  double t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = 0.0;
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double qv = load_partial(p.red + (uint64_t)i * 16 + k);
+      if (k >= 14) t[k] = fmax(t[k], qv); else t[k] += qv;
+    }
+  }
+  {
+    double a[8] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]};
+    block_reduce<8>(a, s_scr, -1);
+    double bq[6] = {t[8], t[9], t[10], t[11], t[12], t[13]};
+    block_reduce<6>(bq, s_scr, -1);
+    const double m0 = wave_max(t[14]), m1 = wave_max(t[15]);
+    if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; }
+    __syncthreads();
+    if (tid == 0) {
+      const double gmax0 = fmax(fmax(s_scr[0], s_scr[2]), fmax(s_scr[4], s_scr[6]));
+      const double gmax1 = fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7]));
+      const double rdot = a[5];
+      const bool plain = (p.restart && rdot > 1E-30) || p.coef == 0.0;        // :231 -- the branch the reference takes
+      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
+      p.out[S_GSUM] = bq[0]; p.out[S_GMAX] = gmax0; p.out[S_RDOT] = rdot;
+      p.out[S_DXDG] = plain ? a[6] : bq[1];
+      p.out[S_DG2] = plain ? a[7] : bq[2];
+      p.out[S_XH2_ADJ] = plain ? a[3] : bq[3];
+      p.out[S_GSUM_ADJ] = plain ? bq[0] : bq[4];
+      p.out[S_GMAX_ADJ] = plain ? gmax0 : gmax1;
+      p.out[S_FSQ_ADJ] = plain ? a[0] : bq[5];
+      p.out[S_ALPHA] = 0.0;
+      p.out[15] = 0.0;
+      __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// out = a + coef*(a - b) elementwise (:242): materialises a lazily-kept iterate for fh_get_vector
+__global__ __launch_bounds__(FH_WG) void k_extrapolate_vec(double* out, const double* a, const double* b, double coef, uint64_t len) {
+  for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < len; i += (uint64_t)gridDim.x * FH_WG)
+    out[i] = coef != 0.0 ? extrapolate(a[i], b[i], coef) : a[i];
+}

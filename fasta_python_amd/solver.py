@@ -178,8 +178,6 @@ class FBSolver:
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
         kind = c.fused_supported() if self.fused_opt is not False else 0
-        if self.accelerate and kind == 2:
-            kind = 0        # FISTA in one pass: dense operator only (the stencil sweep has no place for the restart dot)
         # How the two halves of an iteration reach the device:
         #   "always"      one-pass kernel for every launch of the loop, backtracking retries included: where it costs no more
         #                 than K-fwd alone -- the stencil, and the dense operator from n = 16384 (kind 1: 65536^2 5.0 vs 4.9 ms)
@@ -200,7 +198,7 @@ class FBSolver:
         self.use_fused = self.mode in ("always", "speculative")
         self.fused_always = self.mode == "always"
         if self.fused_opt is True and not self.use_fused:
-            raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator without acceleration")
+            raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
         self.pair_steps = 0

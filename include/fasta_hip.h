@@ -151,7 +151,11 @@ int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, also row-sharded): as fh_step, plus
  * x1 = xprox + c*(xprox - x_accel0) and the gradient taken at z1 + c*(z1 - z_accel0) with c = coef, or 0 when restart != 0
  * and this step's restart dot <x0 - xprox, xprox - x_accel0> (:231) exceeds 1e-30; the dot is returned in FH_S_RDOT and
- * f at the extrapolated point in FH_S_FSQ_ADJ, so the caller updates alpha exactly as after fh_fwd + fh_adj.            */
+ * f at the extrapolated point in FH_S_FSQ_ADJ, so the caller updates alpha exactly as after fh_fwd + fh_adj.
+ * Stencil operator: one sweep as well (csrc/fh_tv.h, k_fused_tv_accel) -- it carries both candidates of the coefficient and
+ * keeps the extrapolated iterate in (prox output, previous prox output, coefficient) form, formed on the fly by the next
+ * sweep; a solve that uses it must use it from the first iteration after fh_init (FH_E_STATE otherwise, and fh_fwd /
+ * fh_adj / fh_step refuse until the next fh_init).  fh_get_vector(X0 | X1 | BEST) materialises the iterate.              */
 int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* scalars);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
  * copies x1 into FH_VEC_BEST (:298-300).                                                         */

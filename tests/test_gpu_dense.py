@@ -239,33 +239,67 @@ def test_full_size_properties_65536():
         op.close()
 
 
-def test_c2_full_size_first_iterations_match_oracle_loop():
-    """BASELINE config 2 at FULL size (65536^2, 32 GiB): the first iterations of the HIP solve against the
-    oracle NumPy loop on a host copy of the same device-generated matrix (BASELINE.md section 4 parity gate:
-    x rtol 1e-5, scalars rtol 1e-8, identical backtrack counts)."""
+def test_c2_c3_full_size_first_iterations_match_oracle_loop():
+    """BASELINE configs 2 (LASSO) and 3 (NNLS) at FULL size (65536^2, 32 GiB): the first FIVE iterations of the HIP solve
+    against the oracle NumPy loop on ONE shared host copy of the same device-generated matrix (BASELINE.md section 4 parity
+    gate: x rtol 1e-5, scalars rtol 1e-8, identical backtrack counts).  The default path at this size is the one-pass kernel."""
     m = n = 65536
-    iters = 3
+    iters = 5
     scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
+    opts = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, record_iterates=True)
     op = fa.DenseMatrixMap.synthetic(m, n, 0, scale)
+    got, rhs = {}, {}
     try:
         x_true = pr.synth_sparse_signal(n, 1)
-        b = op(x_true) + 0.01 * np.random.RandomState(2).randn(m)
-        ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
-        opts = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, record_iterates=True)
-        np.random.seed(3)
-        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", **opts)
-        A = op.host_rows(0, m)                       # 32 GiB host copy, D2H
+        Ax = op(x_true)
+        for kind, sigma in (("lasso", 0.01), ("nnls", 0.005)):          # nn_least_squares.py:49 uses 0.005
+            b = Ax + sigma * np.random.RandomState(2).randn(m)
+            ls, reg = fa.LeastSquares(b), (fa.Shrink(0.02) if kind == "lasso" else fa.NonNeg())
+            solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, **opts)
+            np.random.seed(3)
+            got[kind] = solver.setup().run()
+            assert solver.fused_steps == iters + got[kind].backtracks   # every launch of the loop was the one-pass kernel
+            rhs[kind] = b
+        A = op.host_rows(0, m)                       # 32 GiB host copy, D2H, shared by both oracle runs
     finally:
         op.close()
-    P = pr.sparse_least_squares_from(A, b, 0.02)
-    np.random.seed(3)
-    want = fo.fasta(*P.args7(), **opts)
-    assert got.iteration_count == want.iteration_count == iters
-    assert got.backtracks == want.backtracks
-    for f in ("residuals", "norm_residuals", "stepsizes"):
-        np.testing.assert_allclose(getattr(got, f)[:iters], getattr(want, f)[:iters], rtol=1e-8, err_msg=f)
-    np.testing.assert_allclose(got.objectives[:iters + 1], want.objectives[:iters + 1], rtol=1e-8)
-    np.testing.assert_allclose(got.iterates[:iters + 1], want.iterates[:iters + 1], rtol=1e-5, atol=1e-12)
+    for kind in ("lasso", "nnls"):
+        P = pr.sparse_least_squares_from(A, rhs[kind], 0.02) if kind == "lasso" else pr.nn_least_squares_from(A, rhs[kind])
+        np.random.seed(3)
+        want = fo.fasta(*P.args7(), **opts)
+        g = got[kind]
+        assert g.iteration_count == want.iteration_count == iters, kind
+        assert g.backtracks == want.backtracks, kind
+        for f in ("residuals", "norm_residuals", "stepsizes"):
+            np.testing.assert_allclose(getattr(g, f)[:iters], getattr(want, f)[:iters], rtol=1e-8, err_msg=kind + " " + f)
+        np.testing.assert_allclose(g.objectives[:iters + 1], want.objectives[:iters + 1], rtol=1e-8, err_msg=kind)
+        np.testing.assert_allclose(g.iterates[:iters + 1], want.iterates[:iters + 1], rtol=1e-5, atol=1e-12, err_msg=kind)
+        np.testing.assert_allclose(g.solution, want.solution, rtol=1e-5, atol=1e-12, err_msg=kind)
+
+
+def test_box_prox_inside_a_solve_matches_the_oracle():
+    """Box prox inside full solves on a dense operator: min_y .5||A y - b||^2 subject to 0 <= y <= C, the constraint of the
+    SVM dual (svm.py:71 `np.minimum(np.maximum(y, 0), C)`), in all three modes against the oracle loop running the
+    reference's clip closure."""
+    rng = np.random.RandomState(12)
+    m, n, C = 90, 140, 0.35
+    A = rng.randn(m, n)
+    A /= np.linalg.norm(A, 2)
+    b = A @ rng.uniform(-0.2, 0.6, size=n) + 0.01 * rng.randn(m)
+    for mode in (dict(adaptive=True, accelerate=False), dict(adaptive=False, accelerate=True), dict(adaptive=False, accelerate=False)):
+        opts = dict(tolerance=1e-6, evaluate_objective=True, max_iters=400, **mode)
+        ls, reg = fa.LeastSquares(b), fa.Box(0.0, C)
+        np.random.seed(8)
+        got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", **opts)
+        np.random.seed(8)
+        f = lambda z: .5 * np.linalg.norm((z - b).ravel()) ** 2
+        want = fo.fasta(A, A.T, f, lambda z: z - b, lambda y: 0, lambda y, t: np.minimum(np.maximum(y, 0), C), np.zeros(n), **opts)
+        assert got.iteration_count == want.iteration_count and got.backtracks == want.backtracks, mode
+        k = got.iteration_count
+        G.compare_histories(got, lambda fld: getattr(want, fld), k, rtol=1e-6, atol=1e-13)
+        np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)
+        assert got.solution.min() >= 0.0 and got.solution.max() <= C
+        assert np.any(got.solution == 0.0) and np.any(got.solution == C)        # both faces of the box are active
 
 
 @pytest.mark.parametrize("shape", [(300, 500), (64, 20000), (2000, 16384)])

@@ -126,6 +126,45 @@ def test_tv_denoising_recovers_piecewise_constant_image():
         op.close()
 
 
+@pytest.mark.parametrize("image", [(8192, 8192)])
+def test_c4_full_size_first_iterations_match_oracle_loop(image):
+    """BASELINE config 4 at FULL size (8192^2): the first iterations of the step kernels -- the default one-pass sweep
+    (k_fused_tv_step) and the two-launch pair (k_fwd_tv_step / k_adj_tv_step, fused=False), adaptive and accelerated --
+    against the oracle's NumPy roll-based div/grad loop.  tau0 = 1 is far above 2/L = 1/4 (||div||^2 <= 8), so the first
+    iteration BACKTRACKS (multi-chunk halo rows and the retry path at full size); with L and tau0 given no RNG is drawn."""
+    Hh, Ww = image
+    iters = 4
+    np.random.seed(7)
+    M = pr.checkerboard(Hh, Ww, Hh // 32)
+    M += 0.1 * np.random.standard_normal(M.shape)
+    mu = 0.1
+    P = pr.tv_denoising_from(M, mu)
+    base = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, L=8.0, tau0=1.0)
+    want = {}
+    for name, mode in (("adaptive", dict(adaptive=True, accelerate=False)), ("accelerated", dict(adaptive=False, accelerate=True))):
+        want[name] = (mode, fo.fasta(*P.args7(), **base, **mode))
+        assert want[name][1].backtracks >= 1
+    op = fa.GradDivMap(M.shape)
+    try:
+        ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        for name, (mode, w) in want.items():
+            for fused in ("auto", False):
+                solver = fa.FBSolver(op, ls, reg, P.x0, verbose=False, fused=fused, **base, **mode)
+                got = solver.setup().run()
+                tag = f"{name} fused={fused}"
+                if fused == "auto":
+                    assert solver.fused_steps == iters + got.backtracks, tag      # every launch was the one-pass sweep
+                else:
+                    assert solver.fused_steps == 0, tag
+                assert got.iteration_count == w.iteration_count == iters and got.backtracks == w.backtracks, tag
+                for f in ("residuals", "norm_residuals", "stepsizes"):
+                    np.testing.assert_allclose(getattr(got, f)[:iters], getattr(w, f)[:iters], rtol=1e-8, err_msg=tag + " " + f)
+                np.testing.assert_allclose(got.objectives[:iters + 1], w.objectives[:iters + 1], rtol=1e-8, err_msg=tag)
+                np.testing.assert_allclose(got.solution, w.solution, rtol=1e-5, atol=1e-12, err_msg=tag)
+    finally:
+        op.close()
+
+
 def test_tv_full_size_adjointness_8192():
     """BASELINE config 4 size: <div Y, X> == <Y, grad X> on the 8192^2 stencil (size-independent property)."""
     Hh = Ww = 8192
@@ -198,3 +237,99 @@ def test_tv_solve_identical_with_and_without_the_one_pass_kernel():
     np.testing.assert_allclose(a.residuals[:k], b.residuals[:k], rtol=1e-7)
     np.testing.assert_allclose(a.objectives[:k + 1], b.objectives[:k + 1], rtol=1e-9)
     np.testing.assert_allclose(a.solution, b.solution, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("prox", ["tvball", "identity"])
+@pytest.mark.parametrize("restart", [True, False])
+@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (64, 1000)])
+def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox):
+    """fh_step_accel on the stencil operator (k_fused_tv_accel: both coefficient candidates in one sweep, iterate kept in
+    extrapolated-on-the-fly form) in LOCKSTEP with fh_fwd + fh_adj(accel) on a second context: same alpha recursion, same
+    backtracking-style retry (a launch repeated with a smaller tau before the commit), several restarts along the way.
+    Materialised vectors must be bit-identical (every value is produced by the same IEEE expressions); scalars are sums."""
+    rng = np.random.RandomState(H_ * 11 + W_)
+    M = rng.randn(H_, W_)
+    Y0 = rng.randn(H_, W_, 2) * 0.8
+    one, two = fa.GradDivMap((H_, W_)), fa.GradDivMap((H_, W_))
+    try:
+        for c in (one.ctx, two.ctx):
+            c.set_loss_lsq(M)
+            c.set_prox(hip.PROX_TVBALL if prox == "tvball" else hip.PROX_IDENTITY)
+            c.set_vector(hip.VEC_X0, Y0)
+            c.init()
+        alpha, restarts, best_it = 1.0, 0, None
+        for it in range(25):
+            # With the unit-ball prox the restart rule (:231) never fires on this problem (nor in the reference's own TV runs).
+            # With the identity prox it can be provoked: iterations 10-13 step UPHILL (a negative tau is plain arithmetic to
+            # the kernels) against the downhill momentum, then small downhill steps run against the uphill momentum.
+            tau = -0.05 if 10 <= it <= 13 else (0.01 if it in (14, 15, 16) else 0.1)
+            if prox == "tvball" and tau > 0:
+                tau *= 2.4
+            for attempt in range(2 if it in (1, 4, 14) else 1):        # iterations 1, 4, 14: retry with a smaller step, then commit
+                if attempt:
+                    tau *= 0.5
+                a1 = (1 + np.sqrt(1 + 4 * alpha ** 2)) / 2
+                s1 = one.ctx.step_accel(tau, (alpha - 1) / a1, restart)
+                f2 = two.ctx.fwd(tau)
+                alpha0 = 1.0 if (restart and f2[hip.S_RDOT] > 1e-30) else alpha
+                coef = (alpha0 - 1) / ((1 + np.sqrt(1 + 4 * alpha0 ** 2)) / 2)
+                s2 = two.ctx.adj(tau, True, coef)
+                np.testing.assert_allclose(s1[hip.S_RDOT], f2[hip.S_RDOT], rtol=1e-9, atol=1e-13 * Y0.size)
+                assert (s1[hip.S_RDOT] > 1e-30) == (f2[hip.S_RDOT] > 1e-30)
+                for k in (hip.S_FSQ, hip.S_DXG0, hip.S_DX2, hip.S_XH2, hip.S_G02):
+                    np.testing.assert_allclose(s1[k], f2[k], rtol=1e-11, atol=1e-300, err_msg=f"it {it} fwd scalar {k}")
+                for k in (hip.S_DXDG, hip.S_DG2, hip.S_FSQ_ADJ, hip.S_XH2_ADJ, hip.S_GSUM_ADJ):
+                    np.testing.assert_allclose(s1[k], s2[k], rtol=1e-10, atol=1e-300, err_msg=f"it {it} adj scalar {k}")
+                assert s1[hip.S_GMAX_ADJ] == s2[hip.S_GMAX_ADJ]
+                assert np.array_equal(one.ctx.get_vector(hip.VEC_XPROX, Y0.size), two.ctx.get_vector(hip.VEC_XPROX, Y0.size))
+                assert np.array_equal(one.ctx.get_vector(hip.VEC_Z, M.size), two.ctx.get_vector(hip.VEC_Z, M.size))
+            restarts += int(restart and f2[hip.S_RDOT] > 1e-30)
+            alpha = (1 + np.sqrt(1 + 4 * alpha0 ** 2)) / 2
+            save = it in (0, 2, 5)
+            one.ctx.commit(save_best=save)
+            two.ctx.commit(save_best=save)
+            # the extrapolated iterate is never stored by the one-pass kernel: materialised on demand, same bits
+            assert np.array_equal(one.ctx.get_vector(hip.VEC_X0, Y0.size), two.ctx.get_vector(hip.VEC_X0, Y0.size)), it
+            assert np.array_equal(one.ctx.get_vector(hip.VEC_BEST, Y0.size), two.ctx.get_vector(hip.VEC_BEST, Y0.size)), it
+        if restart and prox == "identity" and H_ * W_ >= 1000:
+            assert 0 < restarts < 25                     # both branches of the restart rule were exercised
+        with pytest.raises(hip.HipError):
+            one.ctx.fwd(0.1)                             # no silent mixing of the two state representations
+        one.ctx.set_vector(hip.VEC_X0, Y0)
+        one.ctx.init()
+        one.ctx.fwd(0.1)                                 # ... a fresh fh_init lifts it
+    finally:
+        one.close()
+        two.close()
+
+
+@pytest.mark.parametrize("restart", [True, False])
+def test_accelerated_tv_solve_identical_with_and_without_the_one_pass_kernel(restart):
+    np.random.seed(9)
+    P = pr.tv_denoising(H=96, W=130, square=16)
+    M, mu = P.data["M"], P.data["mu"]
+    op = fa.GradDivMap(M.shape)
+    try:
+        ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        opts = dict(max_iters=120, tolerance=1e-5, evaluate_objective=True, adaptive=False, accelerate=True, restart=restart,
+                    record_iterates=True)
+        out, used = [], []
+        for fused in (True, False):
+            solver = fa.FBSolver(op, ls, reg, P.x0, verbose=False, fused=fused, **opts)
+            np.random.seed(2)
+            out.append(solver.setup().run())
+            used.append(solver.fused_steps)
+        np.random.seed(2)
+        want = fo.fasta(*P.args7(), **opts)
+    finally:
+        op.close()
+    a, b = out
+    assert used[0] == a.iteration_count + a.backtracks and used[1] == 0
+    assert a.iteration_count == b.iteration_count == want.iteration_count and a.backtracks == b.backtracks == want.backtracks
+    k = a.iteration_count
+    np.testing.assert_allclose(a.residuals[:k], b.residuals[:k], rtol=1e-7)
+    np.testing.assert_allclose(a.objectives[:k + 1], b.objectives[:k + 1], rtol=1e-9)
+    assert np.array_equal(a.iterates[:k + 1], b.iterates[:k + 1]) or np.allclose(a.iterates[:k + 1], b.iterates[:k + 1], rtol=1e-6, atol=1e-10)
+    G.compare_histories(a, lambda f: getattr(want, f), k, rtol=1e-6, atol=1e-13)
+    np.testing.assert_allclose(a.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(a.solution, want.solution, rtol=1e-5, atol=1e-9)

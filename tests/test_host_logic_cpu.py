@@ -57,7 +57,7 @@ def test_driver_reproduces_reference_run(name, fused):
         if "iterates" in z.files:
             np.testing.assert_allclose(c.iterates[:k + 1], z["iterates"][:k + 1], rtol=1e-5, atol=1e-9)
     accelerated = bool(meta["options"].get("accelerate", False))
-    if fused and not (accelerated and meta["kind"] == "tv"):       # FISTA in one pass: dense operator only
+    if fused:                                                      # (FISTA in one pass: dense and stencil operators alike)
         assert ctx.calls["step"] > 0                               # the one-pass path was taken ...
         if fused == 3 and meta["kind"] != "tv" and c.backtracks:
             assert ctx.calls["fwd"] > 0 and ctx.calls["adj"] > 0   # ... and abandoned for the backtracking retries
