@@ -160,6 +160,12 @@ struct fh_ctx {
   int tv_nt = 0;
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
   int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
+  // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
+  // the host fills both with the sentinel only when this signature (workspace, layout) changes or a launch timed out
+  double* slotbuf = nullptr;     // dedicated allocation: the shared workspace `ws` is scribbled over by every other kernel
+  size_t slotbuf_bytes = 0;
+  uint64_t slots_sig = 0;
+  int slots_parity = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
@@ -190,6 +196,7 @@ static void free_operator(fh_ctx* c) {
   fr(c->xhat); fr(c->b); fr(c->zt); fr(c->ZX[0]); fr(c->ZX[1]);
   for (int i = 0; i < 4; ++i) fr(c->T[i]);
   fr(c->ws); c->ws_bytes = 0;
+  fr(c->slotbuf); c->slotbuf_bytes = 0; c->slots_sig = 0;
   c->op = OP_NONE; c->has_b = false;
 }
 
@@ -851,8 +858,9 @@ static FusedShape fused_shape(fh_ctx* c) {
   return sh;
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
-// the one-pass launch beats K-fwd + K-adj once its fixed cost is amortised: wide rows, or at least 32 Mi elements
-static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 25); }
+// the one-pass launch beats K-fwd + K-adj once its fixed cost is amortised: wide rows, or at least 8 Mi elements
+// (profiles/r02_fused_crossover.txt; 32 Mi in round 1, when every launch still refilled its hand-off slots from the host)
+static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 23); }
 
 // the prox kind travels in p.px.kind (run-time switch in the kernel's n-side prologue); FH_PROX_* == PX_* numerically
 template <int PPT, int PIPE, int TEAM>
@@ -871,6 +879,9 @@ struct FusedIO {
   int accel = 0, restart = 0; double coef = 0.0;
   const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr; double* coef_out = nullptr;
 };
+
+// after the synchronisation that follows a one-pass launch: a launch that timed out has left slots un-posted / un-armed
+static inline void fused_after(fh_ctx* c) { if (c->hscal[15] != 0.0) c->slots_sig = 0; }
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const FusedShape sh = fused_shape(c);
@@ -893,15 +904,33 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const unsigned grid = p.nteams * sh.team;
   const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);   // whole 64-byte lines; + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
-  FH_TRY(ensure_ws(c, (slots_elems + gpart_elems + (size_t)grid * 16) * sizeof(double)));
-  p.slots = c->ws; p.gpart = c->ws + slots_elems; p.red = p.gpart + gpart_elems;
+  FH_TRY(ensure_ws(c, (gpart_elems + (size_t)grid * 16) * sizeof(double)));
+  p.gpart = c->ws; p.red = p.gpart + gpart_elems;
+  if (2 * slots_elems * sizeof(double) > c->slotbuf_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->slotbuf) { HIP_TRY(hipFree(c->slotbuf)); c->slotbuf = nullptr; c->slotbuf_bytes = 0; }
+    const size_t bytes = round_up(2 * slots_elems * sizeof(double), 1 << 20);
+    HIP_TRY(hipMalloc((void**)&c->slotbuf, bytes));
+    c->slotbuf_bytes = bytes;
+    c->slots_sig = 0;
+  }
   p.g1 = io.g1;
   p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR; p.variant = c->fused_variant;
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
-  if (sh.team > 1)       // a team of one exchanges nothing: no slot line is ever read
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p.slots, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
-  HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
+  {
+    // signature of everything the slot layout depends on; 0 = "refill" (set after a timed-out launch, see fused_after)
+    uint64_t sig = fh_mix((uint64_t)(uintptr_t)c->slotbuf ^ fh_mix(slots_elems * 131 + (uint64_t)sh.team * 7 + p.nteams)) | 1ull;
+    if (sh.team > 1 && sig != c->slots_sig) {
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
+      HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
+      c->slots_sig = sig;
+      c->slots_parity = 0;
+    }
+    p.slots = c->slotbuf + (size_t)c->slots_parity * slots_elems;
+    p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
+    c->slots_parity ^= 1;
+  }
   if (sh.team == 1) {
     switch (sh.ppt) {
       case 1: launch_fused_p<1, 1, 1>(c, p, grid, io.kind); break;
@@ -962,6 +991,7 @@ static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bo
   FH_TRY(launch_fused_dense(c, 0.0, fio));
   FH_TRY(finish(c));                          // single GPU: the scalar block (incl. the timeout word) is in mapped host memory
   *ok = c->hscal[15] == 0.0;
+  fused_after(c);
   return 0;
 }
 
@@ -1110,7 +1140,7 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // 2 = stencil one-pass kernel (costs no more than K-fwd alone: it simply replaces both launches);
   // 3 = dense one-pass kernel available but NOT recommended: its launch has ~35-50 us of fixed cost (slot fill, n-side
   //     prologue, grid barrier, epilogue), which two short launches under one sync beat on a small matrix
-  //     (profiles/r01d_fused_tuning.txt item 8: 4096^2 81 vs 77 us, 16384 x 4096 140 vs 204 us, 512 x 16384 66 vs 72 us)
+  //     (profiles/r02_fused_crossover.txt: 512 x 1024 35.6 vs 34.9 us, 2048^2 46 vs 53 us, 1024 x 8192 60 vs 63 us, 4096^2 77 vs 76 us)
   const int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
   *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
   return 0;
@@ -1200,7 +1230,9 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
     io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
     FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ));
   }
-  return fetch_scalars(c, scalars);
+  FH_TRY(fetch_scalars(c, scalars));
+  fused_after(c);
+  return 0;
 }
 
 // One-pass iteration WITH acceleration (fasta/__init__.py:220-248): the launch computes this step's restart dot before
@@ -1251,7 +1283,9 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
     io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
     FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ, coef_dev));
   }
-  return fetch_scalars(c, scalars);
+  FH_TRY(fetch_scalars(c, scalars));
+  fused_after(c);
+  return 0;
 }
 
 extern "C" int fh_commit(fh_ctx* c, int save_best) {

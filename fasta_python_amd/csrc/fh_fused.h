@@ -95,15 +95,19 @@ struct FusedP {
   double coef;
   const double* xacc0; const double* zacc0; double* x1;
   double* coef_out;      // optional: the coefficient actually applied (for the separate n-side epilogue of row-sharded runs)
-  double* slots;         // [mp + nteams][max(TEAM, 8)] partial dot products (last nteams lines: restart dot), pre-filled with the sentinel
+  double* slots;         // [mp + nteams][max(TEAM, 8)] partial dot products (last nteams lines: restart dot), holding the sentinel on entry
+  double* slots_next;    // the same array of the NEXT launch: every slot this launch posts is re-armed there with the sentinel, so
+                         // no launch needs a host-side refill (two arrays alternate; the host refills both only when the shape changes)
   double* gpart;         // [nteams][ld]
   double* g1;
   double* red;           // [grid][16] reduction partials
-  unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zeroed before the launch)
+  unsigned* bar;         // [0] grid barrier arrivals, [1] final arrivals   (zero on entry; the finaliser zeroes them again)
   unsigned* err;         // set to 1 on a spin timeout
   int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep between polls, 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
   double* out;
 };
+
+__device__ __forceinline__ double ft_sentinel() { return __hiloint2double((int)FT_SENTINEL_HI, (int)FT_SENTINEL_HI); }
 
 template <int PPT, int NT, int PIPE, int TEAM>
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
@@ -248,8 +252,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // variant bit 64 = FAULT INJECTION for the test-suite: member 7 of team 0 never publishes its first row, so its
     // team-mates must hit the poll budget, raise p.err and let the whole grid drain (no hang)
     const bool sabotage = (p.variant & 64) && team == 0 && mem == TEAM - 1 && r == r_begin;
-    if (lane == 0 && live && !sabotage)
-      store_partial(p.slots + (uint64_t)grow(r) * SL + mem, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+    if (lane == 0 && live && !sabotage) {
+      const uint64_t at = (uint64_t)grow(r) * SL + mem;
+      store_partial(p.slots + at, ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+      store_partial(p.slots_next + at, ft_sentinel());      // fire and forget: read by the launch after this one
+    }
   };
   auto dot_row = [&](const d2 (&buf)[PPT]) -> double {
     double part = 0.0;
@@ -270,6 +277,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // ---------------- FISTA: every team needs this step's restart dot before its first row (the gradient is taken at the
   // extrapolated z): the members exchange their slice sums through the team's extra slot line, summed in member order
   double coef = 0.0, rdot = 0.0;
+  if (TEAM > 1 && tid == 0)      // the restart-dot line of the next launch's array is re-armed whether or not this launch accelerates
+    store_partial(p.slots_next + (uint64_t)(p.mp + team) * (TEAM < 8 ? 8 : TEAM) + mem, ft_sentinel());
   if (p.accel) {
     double w1[1] = {v[6]};
     block_reduce<1>(w1, s_scr, 1);
@@ -545,6 +554,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       p.out[S_ALPHA] = level;
       if (p.coef_out) *p.coef_out = coef;
       p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
+      // leave the counters zero for the next launch (every workgroup is past the grid barrier and has taken its final ticket)
+      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

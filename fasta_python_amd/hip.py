@@ -223,7 +223,7 @@ class HipContext:
         return self._scal.copy()
 
     def fused_supported(self):
-        """0 = none; 1 = dense one-pass kernel, recommended; 3 = dense, available but not recommended (small matrix: n < 16384 and fewer than 32 Mi elements);
+        """0 = none; 1 = dense one-pass kernel, recommended; 3 = dense, available but not recommended (small matrix: n < 16384 and fewer than 8 Mi elements);
         2 = stencil (one sweep replaces both launches)."""
         yes = _i32(0)
         self._call("fh_fused_supported", C.byref(yes))

@@ -145,7 +145,7 @@ int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
  * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it
  * speculatively: if the backtracking test on FH_S_FSQ fails it re-runs fh_fwd (smaller tau) + fh_adj.
  * fh_fused_supported: 0 = no (n > 131072, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
- * 32 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
+ * 8 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, also row-sharded): as fh_step, plus
