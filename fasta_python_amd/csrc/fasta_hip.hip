@@ -367,7 +367,7 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_NT:
       c->tv_nt = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_VARIANT:
-      c->fused_variant = (int)(value & 0xFFFF);
+      c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h); bits 9-10: wide-row candidate
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
@@ -824,7 +824,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 //   n <= 16384 : 4 members x PPT = ceil(n/2048) in 5..8, posts one row ahead
 //   n <= 32768 : 8 members x PPT = ceil(n/4096) in 5..8, posts one row ahead
 //   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead
-//   n <= 131072: 16 members x 16 pieces, exchange in line (three row buffers are all its registers hold)
+//   n <= 131072: 16 members x PPT = ceil(n/8192) in 9..16, x slice in LDS, posts one row ahead (3-4 row buffers)
 // FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536.
 // Teams of 32 (n <= 131072 with posts two or three rows ahead, n <= 262144 in line) were built and measured: a trip costs
 // 1.65 us with 32 members, so they only tie the shapes above / the two-launch path (profiles/r01d_fused_tuning.txt).
@@ -852,7 +852,10 @@ static FusedShape fused_shape(fh_ctx* c) {
   } else if (pieces <= (uint64_t)16 * FH_WG * 8) {
     sh = {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2};
   } else if (pieces <= (uint64_t)16 * FH_WG * 16) {
-    sh = {16, 16, 0};
+    // n in (65536, 131072]: 16 members x 9..16 pieces, posts one row ahead, x slice in LDS
+    // (variant bit 16: the round-1 shape -- 16 pieces, x slice in registers, 3 row buffers, exchange in line)
+    const int ppt = (int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG));
+    sh = (c->fused_variant & 16) ? FusedShape{16, 16, 0} : FusedShape{ppt, 16, 1};
   }
   if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;     // one workgroup per CU, whole teams only
   return sh;
@@ -863,11 +866,11 @@ static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 23); }
 
 // the prox kind travels in p.px.kind (run-time switch in the kernel's n-side prologue); FH_PROX_* == PX_* numerically
-template <int PPT, int PIPE, int TEAM>
+template <int PPT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0>
 static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) {
   (void)kind;
   // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
-  k_fused_dense<PPT, 1, PIPE, TEAM><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  k_fused_dense<PPT, 1, PIPE, TEAM, XLDS, NBO><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 
 // operands of one fused launch; fh_step takes them from the solver state, fh_init / fh_gradient_at pass their own
@@ -955,7 +958,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
       case 7: launch_fused_p<7, 1, 4>(c, p, grid, io.kind); break;
       default: launch_fused_p<8, 1, 4>(c, p, grid, io.kind); break;
     }
-  } else if (sh.team == 8 && sh.pipe) {
+  } else if (sh.team == 8 && sh.pipe > 0) {
     switch (sh.ppt) {
       case 1: launch_fused_p<1, 1, 8>(c, p, grid, io.kind); break;
       case 2: launch_fused_p<2, 1, 8>(c, p, grid, io.kind); break;
@@ -967,15 +970,30 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     }
   } else if (sh.team == 8) {
     launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
-  } else if (sh.team == 16 && sh.pipe) {       // 16 members: posts run two rows ahead of the polls
+  } else if (sh.team == 16 && sh.pipe > 0 && sh.ppt <= 8) {       // 16 members: posts run two rows ahead of the polls
     switch (sh.ppt) {
       case 5: launch_fused_p<5, 2, 16>(c, p, grid, io.kind); break;
       case 6: launch_fused_p<6, 2, 16>(c, p, grid, io.kind); break;
       case 7: launch_fused_p<7, 2, 16>(c, p, grid, io.kind); break;
       default: launch_fused_p<8, 2, 16>(c, p, grid, io.kind); break;
     }
-  } else {
+  } else if (sh.pipe == 0) {
     launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
+  } else {
+    // wide rows, n in (65536, 131072]: 16 members x 9..16 pieces POSTING ONE ROW AHEAD, made possible by keeping the x slice in
+    // LDS (the registers hold 3-4 row buffers and the g1 slice).  Buffer counts are the largest that hipcc allocates without
+    // spilling to scratch (-Rpass-analysis=kernel-resource-usage); measured against the round-1 in-line shape in
+    // profiles/r02_fused_wide.txt: 131072 columns 6.41 -> 4.80 ms (7.16 TB/s), 70000 columns 5.80 -> 2.87 ms.
+    switch (sh.ppt) {
+      case 9:  launch_fused_p<9, 1, 16, 1, 4>(c, p, grid, io.kind); break;
+      case 10: launch_fused_p<10, 1, 16, 1, 4>(c, p, grid, io.kind); break;
+      case 11: launch_fused_p<11, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+      case 12: launch_fused_p<12, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+      case 13: launch_fused_p<13, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+      case 14: launch_fused_p<14, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+      case 15: launch_fused_p<15, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+      default: launch_fused_p<16, 1, 16, 1, 3>(c, p, grid, io.kind); break;
+    }
   }
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());

@@ -109,8 +109,14 @@ struct FusedP {
 
 __device__ __forceinline__ double ft_sentinel() { return __hiloint2double((int)FT_SENTINEL_HI, (int)FT_SENTINEL_HI); }
 
-template <int PPT, int NT, int PIPE, int TEAM>
+// XLDS = 1 (wide rows, PPT 9..16): the member's prox'd x slice lives in LDS (PPT x 4 KiB) instead of PPT x 4 registers per lane.
+// That is what lets these widths POST AHEAD (PIPE = 1) like the narrower ones instead of exchanging in line: with the slice in
+// registers, two hot row buffers + the g1 slice + the x slice exceed what hipcc can keep out of scratch (300-600 spilled
+// registers, 2x slower); with it in LDS and NBO = 3-4 row buffers the loop compiles without spills and streams at the rate of
+// the narrow shapes (n = 131072: 5.36 -> 7.16 TB/s, profiles/r02_fused_wide.txt).
+template <int PPT, int NT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0>      // NBO: number of row buffers (0 = the schedule's default)
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
+  __shared__ __attribute__((aligned(16))) d2 s_x[XLDS ? PPT * FH_WG : 1];
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_part2[2][4];  // TEAM == 1: wave partials, double-buffered by trip parity
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   const double level = (kind == PX_LINF || kind == PX_L1BALL) ? *p.px.level : 0.0;
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
-  d2 xq[PPT];
+  d2 xq[XLDS ? 1 : PPT];
   double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax (team 0 only); [6]: restart dot (every team)
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
         v[5] = fmax(v[5], fabs(xpe));
       }
     }
-    xq[k] = xp;
+    if (XLDS) s_x[k * FH_WG + tid] = xp; else xq[XLDS ? 0 : k] = xp;      // (each lane only ever reads back its own entries)
     if (team == 0 && c < p.ld2) {   // write-through: other workgroups read these back after the grid barrier
       store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
       store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      part = fma(buf[k].x, xq[k].x, part);
-      part = fma(buf[k].y, xq[k].y, part);
+      const d2 xv = XLDS ? s_x[k * FH_WG + tid] : xq[XLDS ? 0 : k];
+      part = fma(buf[k].x, xv.x, part);
+      part = fma(buf[k].y, xv.y, part);
     }
     return ft_wave_sum(part);
   };
@@ -331,11 +338,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       }
     }
   } else if constexpr (!PIPE) {
-    // ---- exchange in line: prefetch r+2 | dot r | exchange r | update r  (two rows in flight during the exchange)
-    auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // r < r_end, uniform over the workgroup
+    // ---- exchange in line: prefetch r+NB-1 | dot r | exchange r | update r  (NB-1 rows in flight during the exchange)
+    auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // uniform over the workgroup; r >= r_end: phantom
+      const bool live = r < r_end;
+      const uint32_t gr = grow(min(r, r_last));
       load_row(nbuf, min(nr, r_last));
-      const double bi = bq[grow(r)];
-      const double za = p.accel ? zq[grow(r)] : 0.0;
+      const double bi = bq[gr];
+      const double za = p.accel ? zq[gr] : 0.0;
       FT_T(0);
       const double part = dot_row(buf);
       FT_T(1);
@@ -343,13 +352,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       ft_lds_barrier();
       FT_T(2);
       if (wave == 0) {
-        post_row(r, true);
+        post_row(min(r, r_last), live);
         FT_T(3);
-        const double zs = poll_line(grow(r), true);
+        const double zs = poll_line(gr, live);
         FT_T(4);
         if (lane == 0) {
-          s_bc[0] = loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss);
-          if (mem == 0) store_partial(p.z + grow(r), zs);              // read back below by other lanes of this workgroup
+          s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
+          if (mem == 0 && live) store_partial(p.z + gr, zs);            // read back below by other lanes of this workgroup
         }
       }
       FT_T(5);
@@ -359,18 +368,17 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       FT_T(7);
     };
     if (r_begin < r_end) {
-      d2 b0[PPT], b1[PPT], b2[PPT];
-      load_row(b0, r_begin);
-      load_row(b1, min(r_begin + 1u, r_last));
-      uint32_t r = r_begin;
-      for (; r + 3u <= r_end; r += 3u) {              // branch-free body: exact vmcnt distances (two rows stay in flight)
-        process_row(b0, r, b2, r + 2u);
-        process_row(b1, r + 1u, b0, r + 3u);
-        process_row(b2, r + 2u, b1, r + 4u);
-      }
-      if (r < r_end) {
-        process_row(b0, r, b2, r + 2u);
-        if (r + 1u < r_end) process_row(b1, r + 1u, b0, r + 3u);
+      // NB rotating buffers: one row is worked on, NB-1 rows of loads stay in flight across the exchange.  Three buffers of 16
+      // pieces are all the registers hold next to the x slice; with the slice in LDS (XLDS) there is room for four or five.
+      // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
+      constexpr int NB = NBO ? NBO : 3;
+      d2 B[NB][PPT];
+      const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+#pragma unroll
+      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+      for (uint32_t t = 0; t < trips; t += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) process_row(B[j], r_begin + t + j, B[(j + NB - 1) % NB], r_begin + t + j + (NB - 1u));
       }
     }
   } else if (r_begin < r_end) {
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // NB register buffers rotate: row t is held until its update, row t+1 until the next trip, NB-2 rows prefetch.
     // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
     constexpr int D = PIPE;                                        // rows between a post and its poll
-    constexpr int NB = PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6);         // D+1 rows are held, NB-1-D rows prefetch
+    constexpr int NB = NBO ? NBO : (PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6));     // D+1 rows are held, NB-1-D rows prefetch
     static_assert(NB >= D + 2, "need at least one prefetching buffer");
     d2 B[NB][PPT];
     const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;

@@ -4,7 +4,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import fasta_python_amd as fa
 from fasta_python_amd import hip, synthetic
-for n, m in ((131072, 32768), (100000, 32768), (262144, 16384)):
+for n, m in ((131072, 32768), (120000, 32768), (110000, 32768), (100000, 32768), (90000, 32768), (80000, 32768), (70000, 32768), (66000, 32768), (65536, 32768)):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)
@@ -12,7 +12,7 @@ for n, m in ((131072, 32768), (100000, 32768), (262144, 16384)):
     ctx.set_vector(hip.VEC_X0, rng.randn(n) * 0.01)
     ctx.init()
     out = []
-    for v in (2, 18, 10):
+    for v in (2, 18):       # 2 = default (n > 65536: x slice in LDS, posting one row ahead), 18 = round-1 shape (16 pieces in registers, 3 buffers, exchange in line)
         ctx.set_tuning(hip.TUNE_FUSED_VARIANT, v)
         ctx.step(0.2)
         ctx.timing_reset(); ctx.timing_enable(True)

@@ -22,12 +22,13 @@ def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
 
 
 # variant bits: 2 = team members on one XCD (default), 0 = consecutive blocks, 8 = n=65536 as 8 members x 16 pieces with the
-# exchange in line (default there: 16 members x 8 pieces, posts two rows ahead); n in (65536, 131072] runs 16 x 16 in line
-@pytest.mark.parametrize("variant", [2, 0, 10])
+# exchange in line (default there: 16 members x 8 pieces, posts two rows ahead); n in (65536, 131072] runs 16 members x 9..16 pieces
+# with the x slice in LDS, posting one row ahead (variant bit 16: the round-1 shape, 16 x 16 in line)
+@pytest.mark.parametrize("variant", [2, 0, 10, 18])
 @pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384), (130, 32768),
                                  (70, 65536), (40, 131072),
                                  # ragged n: the next shape up with the surplus lanes masked
-                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000), (24, 100000)])
+                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000), (25, 75000), (21, 90000), (24, 100000), (23, 108000), (19, 120000)])
 def test_fused_step_equals_two_launch_step(m, n, variant):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -93,7 +94,7 @@ def test_fused_step_with_the_logistic_loss_equals_two_launch_step(m, n):
 
 
 @pytest.mark.parametrize("loss", ["lsq", "logistic"])
-@pytest.mark.parametrize("m,n,restart", [(300, 4096, True), (300, 4096, False), (64, 65536, True), (90, 20000, True), (2500, 8192, False)])
+@pytest.mark.parametrize("m,n,restart", [(300, 4096, True), (300, 4096, False), (64, 65536, True), (90, 20000, True), (2500, 8192, False), (50, 100000, True), (45, 131072, False)])
 def test_fused_accelerated_step_equals_two_launch_step(m, n, restart, loss):
     """fh_step_accel: restart dot before the first row, gradient at the extrapolated z, x1 extrapolated (FISTA)."""
     rng = np.random.RandomState(m + n)
