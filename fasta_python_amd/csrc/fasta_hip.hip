@@ -816,7 +816,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 
 // ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
 // Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row; lanes past the row's last
-// piece are masked (clamped loads, zero x), so any n up to 131072 fits the next shape up.  A member's piece of a row is
+// piece are masked (clamped loads, zero x), so any n up to 262144 fits the next shape up.  A member's piece of a row is
 // kept at 5..8 pieces per lane (20-32 KiB per workgroup per row) by choosing the team size -- fewer members means more
 // teams, i.e. fewer rows (trips of ~0.7-1.2 us) per team:
 //   n <= 4096  : 1 member  (a workgroup owns whole rows: no exchange), PPT = ceil(n/512) rounded up to 1, 2, 4, 5..8
@@ -825,9 +825,10 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 //   n <= 32768 : 8 members x PPT = ceil(n/4096) in 5..8, posts one row ahead
 //   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead
 //   n <= 131072: 16 members x PPT = ceil(n/8192) in 9..16, x slice in LDS, posts one row ahead (3-4 row buffers)
-// FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536.
-// Teams of 32 (n <= 131072 with posts two or three rows ahead, n <= 262144 in line) were built and measured: a trip costs
-// 1.65 us with 32 members, so they only tie the shapes above / the two-launch path (profiles/r01d_fused_tuning.txt).
+//   n <= 262144: 32 members x PPT = ceil(n/16384) in 9..16, same schedule (6.1 TB/s at n = 262144: a trip with 32 members is
+//                slower, but still 1.8x the two-launch path)
+// FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536;
+// bit 16: n in (65536, 131072] as in round 1 (16 members x 16 pieces in registers, exchange in line).
 struct FusedShape { int ppt, team, pipe; };
 static FusedShape fused_shape(fh_ctx* c) {
   FusedShape none = {0, 0, 0};
@@ -856,6 +857,9 @@ static FusedShape fused_shape(fh_ctx* c) {
     // (variant bit 16: the round-1 shape -- 16 pieces, x slice in registers, 3 row buffers, exchange in line)
     const int ppt = (int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG));
     sh = (c->fused_variant & 16) ? FusedShape{16, 16, 0} : FusedShape{ppt, 16, 1};
+  } else if (pieces <= (uint64_t)32 * FH_WG * 16) {
+    // n in (131072, 262144]: 32 members (a whole XCD per team, 8 teams) x 9..16 pieces, same schedule
+    sh = {(int)((pieces + 32 * FH_WG - 1) / (32 * FH_WG)), 32, 1};
   }
   if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;     // one workgroup per CU, whole teams only
   return sh;
@@ -888,7 +892,7 @@ static inline void fused_after(fh_ctx* c) { if (c->hscal[15] != 0.0) c->slots_si
 
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const FusedShape sh = fused_shape(c);
-  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 131072 and a scalar-separable prox)");
+  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 262144 and a scalar-separable prox)");
   FusedP p;
   p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.nteams = (uint32_t)(c->ncu / sh.team);
@@ -905,7 +909,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.px.kind = io.kind;
   p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
   const unsigned grid = p.nteams * sh.team;
-  const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);   // whole 64-byte lines; + one line per team for the restart dot
+  const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);     // (32 members: four 64-byte lines per row)   // whole 64-byte lines; + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
   FH_TRY(ensure_ws(c, (gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.gpart = c->ws; p.red = p.gpart + gpart_elems;
@@ -979,6 +983,17 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     }
   } else if (sh.pipe == 0) {
     launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
+  } else if (sh.team == 32) {
+    switch (sh.ppt) {
+      case 9:  launch_fused_p<9, 1, 32, 1, 4>(c, p, grid, io.kind); break;
+      case 10: launch_fused_p<10, 1, 32, 1, 4>(c, p, grid, io.kind); break;
+      case 11: launch_fused_p<11, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+      case 12: launch_fused_p<12, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+      case 13: launch_fused_p<13, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+      case 14: launch_fused_p<14, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+      case 15: launch_fused_p<15, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+      default: launch_fused_p<16, 1, 32, 1, 3>(c, p, grid, io.kind); break;
+    }
   } else {
     // wide rows, n in (65536, 131072]: 16 members x 9..16 pieces POSTING ONE ROW AHEAD, made possible by keeping the x slice in
     // LDS (the registers hold 3-4 row buffers and the g1 slice).  Buffer counts are the largest that hipcc allocates without

@@ -36,12 +36,12 @@
 // the backtracking test fails the driver re-runs K-fwd with the smaller step and K-adj: identical results either way).
 // With acceleration (p.accel, fh_step_accel) the FISTA coefficient depends on this launch's own restart dot: every team
 // exchanges it through one extra slot line before its first row.
-// Requires n <= 131072: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
+// Requires n <= 262144: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
 // address, carry x = 0 and are masked out of every store (fasta_hip.hip:fused_shape picks the next shape up).
 #pragma once
 #include "fh_dense.h"
 
-#define FT_TEAM_MAX 16                              // members per team: 1, 2, 4, 8 or 16 (template parameter TEAM; 32 works, see fused_shape)
+#define FT_TEAM_MAX 32                              // members per team: 1, 2, 4, 8, 16 or 32 (template parameter TEAM)
 #define FT_SENTINEL_HI 0x7FF8DEADu                  // slot filler: the NaN 0x7FF8DEAD7FF8DEAD (hipMemsetD32)
 #define FT_SPIN_TICKS 50000000ull                   // 0.5 s of the 100 MHz s_memrealtime clock (grid barrier)
 #define FT_SPIN_POLLS 1000000u                      // slot-poll budget: ~0.3-0.5 us per poll (s_load glc + s_sleep) => ~0.4 s

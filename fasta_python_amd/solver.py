@@ -198,7 +198,7 @@ class FBSolver:
         self.use_fused = self.mode in ("always", "speculative")
         self.fused_always = self.mode == "always"
         if self.fused_opt is True and not self.use_fused:
-            raise ValueError("fused=True needs a dense operator with n <= 131072, or a stencil operator")
+            raise ValueError("fused=True needs a dense operator with n <= 262144, or a stencil operator")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
         self.fused_steps = 0
         self.pair_steps = 0

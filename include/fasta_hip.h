@@ -144,7 +144,7 @@ int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
  * (teams of 1 to 16 co-resident workgroups cover a row and exchange partial dot products; see csrc/fh_fused.h).  Writes the complete
  * FH_S_* block (both halves); scalars[15] != 0 reports a bounded-spin timeout (results invalid).  The caller uses it
  * speculatively: if the backtracking test on FH_S_FSQ fails it re-runs fh_fwd (smaller tau) + fh_adj.
- * fh_fused_supported: 0 = no (n > 131072, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
+ * fh_fused_supported: 0 = no (n > 262144, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
  * 8 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);

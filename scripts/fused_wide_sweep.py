@@ -4,7 +4,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import fasta_python_amd as fa
 from fasta_python_amd import hip, synthetic
-for n, m in ((131072, 32768), (120000, 32768), (110000, 32768), (100000, 32768), (90000, 32768), (80000, 32768), (70000, 32768), (66000, 32768), (65536, 32768)):
+for n, m in ((262144, 16384), (200000, 16384), (150000, 16384), (131072, 32768), (120000, 32768), (110000, 32768), (100000, 32768), (90000, 32768), (80000, 32768), (70000, 32768), (66000, 32768), (65536, 32768)):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)

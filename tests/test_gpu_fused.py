@@ -28,7 +28,9 @@ def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
 @pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384), (130, 32768),
                                  (70, 65536), (40, 131072),
                                  # ragged n: the next shape up with the surplus lanes masked
-                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000), (25, 75000), (21, 90000), (24, 100000), (23, 108000), (19, 120000)])
+                                 (9, 100), (50, 5000), (120, 9001), (40, 20000), (33, 33000), (30, 50000), (20, 70000), (25, 75000), (21, 90000), (24, 100000), (23, 108000), (19, 120000),
+                                 # 32 members (n in (131072, 262144])
+                                 (14, 140000), (12, 200000), (10, 262144)])
 def test_fused_step_equals_two_launch_step(m, n, variant):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -137,7 +139,7 @@ def test_fused_accelerated_step_equals_two_launch_step(m, n, restart, loss):
 
 
 def test_unsupported_shape_reports_and_auto_falls_back():
-    n = 131072 + 16                                # a row no longer fits 16 members x 16 pieces x 256 lanes
+    n = 262144 + 16                                # a row no longer fits 32 members x 16 pieces x 256 lanes
     A = np.random.RandomState(0).randn(3, n) / 400
     op = fa.DenseMatrixMap(A)
     try:
