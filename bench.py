@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--tune", default="", help="comma list key=value of FH_TUNE_* integers, e.g. 3=2,0=8")
     ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"],
                     help="one-pass iteration kernel (fh_step): auto = when the shape supports it")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
+                    help="device storage of A: f64 (default, the headline) or f32 (opt-in throughput mode; arithmetic stays float64)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="rendezvous, broadcast, barrier and max-over-ranks only -- no GPU work (CPU rehearsal of --gpus N)")
     return ap.parse_args(argv)
@@ -249,11 +251,12 @@ def kernel_table(per):
     return dom, table
 
 
-def dense_bytes(m, n):
+def dense_bytes(m, n, esize=8):
     """Algorithmic HBM bytes per launch of the three dense kernels (SURVEY.md 8(d) vector terms):
     K-fwd reads A, x0, g0, b and writes xhat, xprox, z; K-adj reads A, z, b, x0, xprox, xhat, g... ; the one-pass kernel
-    reads A ONCE and moves the union of both vector sets (3m + 7n)."""
-    return {"fwd": (m * n + 4 * n + 2 * m) * 8, "adj": (m * n + 2 * m + 5 * n) * 8, "fused": (m * n + 3 * m + 7 * n) * 8}
+    reads A ONCE and moves the union of both vector sets (3m + 7n).  esize = bytes per stored element of A (vectors: 8)."""
+    return {"fwd": m * n * esize + (4 * n + 2 * m) * 8, "adj": m * n * esize + (2 * m + 5 * n) * 8,
+            "fused": m * n * esize + (3 * m + 7 * n) * 8}
 
 
 def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False):
@@ -273,7 +276,7 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
                          max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
     np.random.seed(3)           # same Lipschitz probes on every rank
     t = timed_steps(solver, ctx, grp, warmup, steps)
-    by = dense_bytes(m_local, n)
+    by = dense_bytes(m_local, n, 4 if getattr(A, "storage", "f64") == "f32" else 8)
     per = {"fasta_fwd(k_fwd_dense)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_dense)": t["k"]["adj"] + (by["adj"],),
            "fasta_step(k_fused_dense)": t["k"]["fused"] + (by["fused"],)}
     dom, table = kernel_table(per)
@@ -331,7 +334,7 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
     P = side * side
     by = tv_bytes(P, accelerate)
     per = {"fasta_fwd(k_fwd_tv_step)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_tv_step)": t["k"]["adj"] + (by["adj"],),
-           "fasta_step(k_fused_tv_step)": t["k"]["fused"] + (by["fused"],)}
+           ("fasta_step_accel(k_fused_tv_accel)" if accelerate else "fasta_step(k_fused_tv_step)"): t["k"]["fused"] + (by["fused"],)}
     dom, table = kernel_table(per)
     model_bytes = (steps * 136 + t["backtracks"] * 64) * P
     return {
@@ -356,7 +359,7 @@ def tv_line(args, r, accelerate):
         "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), {'FISTA' if accelerate else 'adaptive FBS'} with backtracking",
                    "backtracks_in_timed_steps": r["backtracks"], "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GB/s"] / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("k_fused_tv_step" if "fused" in r["dominant"] else
+                     "traffic": pmc_traffic(("k_fused_tv_accel" if accelerate else "k_fused_tv_step") if "fused" in r["dominant"] else
                                             ("k_fwd_tv_step" if "fwd" in r["dominant"] else "k_adj_tv_step"))[0] if side == 8192 else None,
                      "kernel": r["dominant"], "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "per_kernel": r["per_kernel"], "loop_GB/s_wallclock": r["loop_GB/s_wallclock"],
@@ -396,11 +399,11 @@ def main(argv=None):
         k, v = item.split("=")
         tuning[int(k)] = int(v)
 
-    def shard(m_all):
+    def shard(m_all, storage=None):
         """This rank's row block of the synthetic (m_all x n) matrix, generated in HBM, with the RCCL communicator attached."""
         rows = m_all // grp.world
         A = fa.DenseMatrixMap.synthetic(rows, n, seed=0, scale=synthetic.lasso_scale(m_all, n), row0=grp.rank * rows,
-                                        m_total=m_all, device=grp.local_rank, tuning=tuning)
+                                        m_total=m_all, device=grp.local_rank, tuning=tuning, storage=storage or args.storage)
         if grp.world > 1 or grp.force:
             uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
             A.ctx.comm_init(grp.world, grp.rank, uid)
@@ -429,9 +432,9 @@ def main(argv=None):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f64" if args.storage == "f64" else "f32-storage (A stored float32; vectors, accumulation, scalars float64)",
         "data": "synthetic",
-        "config": {"workload": f"{names[0]} dense A {m_total}x{n} float64, {names[1]} prox, "
+        "config": {"workload": f"{names[0]} dense A {m_total}x{n} {'float64' if args.storage == 'f64' else 'float32-storage'}, {names[1]} prox, "
                                f"{'FISTA' if args.accelerate else 'adaptive FBS'} with backtracking"
                                + (f", row-sharded over {grp.world} GPUs ({m_local} rows each)" if grp.world > 1 else ""),
                    "m": m_total, "n": n, "prox": "shrink" if args.workload == "lasso" else "nonneg", "mu": main_r["mu"],
@@ -457,7 +460,7 @@ def main(argv=None):
     }
 
     extra = {}
-    if not args.no_extra and not args.accelerate and args.workload == "lasso":
+    if not args.no_extra and not args.accelerate and args.workload == "lasso" and args.storage == "f64":
         if fused is not False and main_r["fused_steps"]:
             r = run_dense(args, grp, A, m_total, n, "lasso", False, args.steps, args.warmup)
             extra["lasso_two_launch"] = sub_result(r, f"LASSO {m_total}x{n}, two launches per iteration (K-fwd + K-adj, the north-star structure)")
@@ -474,6 +477,17 @@ def main(argv=None):
             s["comm_avg_ms"], s["ranks_seen"] = r["comm_avg_ms"], ctx.comm_count()
             extra["config5_shard"] = s
         else:
+            # opt-in float32-storage mode on the same synthetic matrix (rounded to float32): a SEPARATE line, never the headline
+            A32 = shard(m_total, "f32")
+            try:
+                r = run_dense(args, grp, A32, m_total, n, "lasso", fused, args.steps, args.warmup)
+            finally:
+                A32.close()
+            s32 = sub_result(r, f"LASSO {m_total}x{n}, A stored float32 (opt-in; vectors, accumulation and scalars float64)")
+            s32["dtype"] = "f32-storage"
+            s32["tolerance"] = ("iterates equal the reference's run on A.astype(float32) to the float64 path's tolerances; against the "
+                                "float64-matrix run they differ by the rounding of A (<= 3e-7 relative away from the chaotic regime)")
+            extra["lasso_f32_storage"] = s32
             for key, acc in (("tv", False), ("tv_accelerated", True)):
                 r = run_tv(args, grp, args.steps, args.warmup, "auto", acc)
                 s = sub_result(r, f"TV denoising {args.image}x{args.image} (BASELINE config 4), "
@@ -482,7 +496,7 @@ def main(argv=None):
                 extra[key] = s
     if extra:
         result["extra"] = extra
-    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline and args.workload == "lasso" and not args.accelerate:
+    if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline and args.workload == "lasso" and not args.accelerate and args.storage == "f64":
         result["cpu_baseline"] = cpu_baseline(A, main_r["b"], main_r["mu"], n, m_total, args.cpu_rows, args.cpu_iters, args.cpu_repeats)
     if grp.rank == 0:
         print(json.dumps(result))

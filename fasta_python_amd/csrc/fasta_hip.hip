@@ -103,7 +103,8 @@ struct fh_ctx {
   int op = OP_NONE;
   bool op_pending_stencil = false;
   uint64_t m = 0, n = 0;     // logical (local) rows / columns of A   (stencil: m = H*W, n = 2*H*W)
-  uint64_t mp = 0, ld = 0;   // padded rows, device leading dimension (dense)
+  uint64_t mp = 0, ld = 0;   // padded rows, device leading dimension in elements (dense)
+  int f32 = 0;               // storage of A: 0 = float64, 1 = float32 (opt-in, fh_create_ex; vectors and arithmetic stay float64)
   uint64_t nv = 0, mv = 0;   // allocated n-side / m-side vector lengths (doubles)
   uint64_t H = 0, W = 0;
   double* A = nullptr;
@@ -314,6 +315,16 @@ extern "C" int fh_create(int device, fh_ctx** out) {
   return 0;
 }
 
+// SURVEY.md 8(b) form of the constructor: device list + storage type of A.  One process drives one GPU in this design
+// (row sharding = one context per process + RCCL), so ndev must be 1.
+extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out) {
+  if (ndev != 1 || !dev_ids) return fail(FH_E_ARG, "fh_create_ex: one device per context (got ndev = %d); row sharding uses one process per GPU and fh_comm_init", ndev);
+  if (dtype != FH_DTYPE_F64 && dtype != FH_DTYPE_F32_STORAGE) return fail(FH_E_ARG, "fh_create_ex: unknown dtype %d", dtype);
+  FH_TRY(fh_create(dev_ids[0], out));
+  (*out)->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
+  return 0;
+}
+
 extern "C" int fh_comm_destroy(fh_ctx* c);
 
 extern "C" int fh_destroy(fh_ctx* c) {
@@ -353,7 +364,7 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       if (value != 0 && value != 1 && value != 2 && value != 4) return fail(FH_E_ARG, "ADJ_CPT must be 0 (auto), 1, 2 or 4");
       c->adj_cpt = (int)value; return 0;
     case FH_TUNE_LD_PAD:
-      if (value < 0 || value % 16) return fail(FH_E_ARG, "LD_PAD must be a non-negative multiple of 16");
+      if (value < 0 || value % 32) return fail(FH_E_ARG, "LD_PAD must be a non-negative multiple of 32");
       if (c->op != OP_NONE) return fail(FH_E_STATE, "LD_PAD must be set before the matrix");
       c->ld_pad = (int)value; return 0;
     case FH_TUNE_NT_LOADS:
@@ -385,9 +396,9 @@ static int setup_dense(fh_ctx* c, uint64_t m, uint64_t n) {
   free_operator(c);
   c->m = m; c->n = n;
   c->mp = round_up(m, 16);
-  c->ld = round_up(n, 16) + (uint64_t)c->ld_pad;
+  c->ld = round_up(n, c->f32 ? 32 : 16) + (uint64_t)c->ld_pad;      // rows stay 128-byte aligned in either storage
   c->nv = c->ld; c->mv = c->mp;
-  HIP_TRY(hipMalloc((void**)&c->A, c->mp * c->ld * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&c->A, c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double))));
   FH_TRY(alloc_vectors(c));
   c->op = OP_DENSE;
   return 0;
@@ -397,9 +408,25 @@ extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n,
   if (!c || !A) return fail(FH_E_ARG, "fh_set_matrix: null argument");
   if (ld_host < n) return fail(FH_E_ARG, "fh_set_matrix: ld_host %llu < n %llu", (unsigned long long)ld_host, (unsigned long long)n);
   FH_TRY(setup_dense(c, m, n));
-  HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * sizeof(double), c->stream));
-  HIP_TRY(hipMemcpy2DAsync(c->A, c->ld * sizeof(double), A, ld_host * sizeof(double), n * sizeof(double), m,
-                           hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double)), c->stream));
+  if (!c->f32) {
+    HIP_TRY(hipMemcpy2DAsync(c->A, c->ld * sizeof(double), A, ld_host * sizeof(double), n * sizeof(double), m,
+                             hipMemcpyHostToDevice, c->stream));
+    return finish(c);
+  }
+  // float32 storage: float64 row blocks go through a staging buffer and are rounded on the device (round to nearest even)
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(m, ((uint64_t)64 << 20) / (n * sizeof(double))));
+  double* stage = nullptr;
+  HIP_TRY(hipMalloc((void**)&stage, chunk * n * sizeof(double)));
+  for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
+    const uint64_t rows = std::min<uint64_t>(chunk, m - r0);
+    HIP_TRY(hipMemcpy2DAsync(stage, n * sizeof(double), A + r0 * ld_host, ld_host * sizeof(double), n * sizeof(double), rows,
+                             hipMemcpyHostToDevice, c->stream));
+    k_rows_to_f32<<<dim3(2048), dim3(FH_WG), 0, c->stream>>>(stage, n, reinterpret_cast<float*>(c->A) + r0 * c->ld, c->ld, (uint32_t)rows, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));      // the host block may be pageable: finish before the next chunk reuses `stage`
+  }
+  (void)hipFree(stage);
   return finish(c);
 }
 
@@ -407,8 +434,8 @@ extern "C" int fh_generate_matrix(fh_ctx* c, uint64_t m, uint64_t n, uint64_t ro
   if (!c) return fail(FH_E_ARG, "null context");
   FH_TRY(setup_dense(c, m, n));
   const uint64_t key = fh_mix(seed);
-  k_gen_matrix<<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, c->ld, (uint32_t)(c->ld / 2), (uint32_t)m, (uint32_t)c->mp,
-                                                          (uint32_t)n, row0, key, coef);
+  if (c->f32) k_gen_matrix<1><<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, (uint32_t)(c->ld / 4), (uint32_t)m, (uint32_t)c->mp, (uint32_t)n, row0, key, coef);
+  else k_gen_matrix<0><<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, (uint32_t)(c->ld / 2), (uint32_t)m, (uint32_t)c->mp, (uint32_t)n, row0, key, coef);
   HIP_TRY(hipGetLastError());
   return finish(c);
 }
@@ -419,8 +446,23 @@ extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, doub
   if (row0 + nrows > c->m) return fail(FH_E_ARG, "rows [%llu,%llu) out of range (m=%llu)", (unsigned long long)row0,
                                        (unsigned long long)(row0 + nrows), (unsigned long long)c->m);
   FH_TRY(use_device(c));
-  HIP_TRY(hipMemcpy2DAsync(out, c->n * sizeof(double), c->A + row0 * c->ld, c->ld * sizeof(double), c->n * sizeof(double),
-                           nrows, hipMemcpyDeviceToHost, c->stream));
+  if (!c->f32) {
+    HIP_TRY(hipMemcpy2DAsync(out, c->n * sizeof(double), c->A + row0 * c->ld, c->ld * sizeof(double), c->n * sizeof(double),
+                             nrows, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+  }
+  // float32 storage: widen on the device (exact), row blocks through a staging buffer
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nrows, ((uint64_t)64 << 20) / (c->n * sizeof(double))));
+  double* stage = nullptr;
+  HIP_TRY(hipMalloc((void**)&stage, chunk * c->n * sizeof(double)));
+  for (uint64_t r0 = 0; r0 < nrows; r0 += chunk) {
+    const uint64_t rows = std::min<uint64_t>(chunk, nrows - r0);
+    k_rows_from_f32<<<dim3(2048), dim3(FH_WG), 0, c->stream>>>(reinterpret_cast<const float*>(c->A) + (row0 + r0) * c->ld, c->ld, stage, c->n, (uint32_t)rows, (uint32_t)c->n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out + r0 * c->n, stage, rows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  (void)hipFree(stage);
   return finish(c);
 }
 
@@ -568,7 +610,11 @@ static ProxP make_prox(fh_ctx* c, double tau) {
 
 template <int R, int KIND>
 static void launch_fwd_rk(fh_ctx* c, const FwdP& p, unsigned grid) {
-  if (c->nt_loads) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->f32) {                                   // float32 storage: non-temporal loads only, R = 4 or 8
+    if constexpr (R == 16) k_fwd_dense<8, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+    else k_fwd_dense<R, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  }
+  else if (c->nt_loads) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_fwd_dense<R, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 template <int R>
@@ -588,12 +634,15 @@ static void launch_fwd_r(fh_ctx* c, const FwdP& p, unsigned grid, int kind) {
 static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
                             double* xhat, double* xp, double* z, int sub_b) {
   // rows per pass (sweep, profiles/r01_tune_sizes.txt): 4 up to n = 32768, 8 beyond
-  const int R = c->fwd_rows ? c->fwd_rows : (c->ld <= 32768 ? 4 : 8);
+  // float32 storage: the x0/g0 pieces of a trip are twice as many per byte of A, so it takes 8 rows per pass from n = 32768 on
+  // to keep as many bytes of A in flight (4 rows: 4.7 TB/s at 65536^2, profiles/r02_f32_storage.txt)
+  int R = c->fwd_rows ? c->fwd_rows : (c->ld <= (c->f32 ? 16384u : 32768u) ? 4 : 8);
+  if (c->f32 && R == 16) R = 8;
   if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
   FwdP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / (c->f32 ? 4 : 2)); p.nv2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m;
   p.nrg = (uint32_t)(c->mp / R);
-  p.nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
+  p.nchunks = (p.nv2 + FH_WG - 1) / FH_WG;
   p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp;
   p.b = c->b; p.z = z; p.tau = tau; p.sub_b = sub_b; p.loss = c->loss_kind;
   p.px = make_prox(c, tau);
@@ -620,7 +669,8 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
 
 template <int CPT>
 static void launch_adj_c(fh_ctx* c, const AdjP& p, unsigned grid) {
-  if (c->nt_loads) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->f32) k_adj_dense<CPT, 1, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else if (c->nt_loads) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_adj_dense<CPT, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 
@@ -632,7 +682,8 @@ struct AdjIO {
 
 static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   AdjP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / 2); p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp; p.m = (uint32_t)c->m;
+  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / (c->f32 ? 4 : 2)); p.nv2 = (uint32_t)(c->nv / 2);
+  p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp; p.m = (uint32_t)c->m;
   // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): about 32 slabs
   // (more when there are few column chunks, so that >= 128 workgroups exist), slabs of 32..2048 rows, and
   // column chunks of 2 x 16 B per lane below n = 32768, 4 x 16 B from there on (1 x for n <= 1024).
@@ -641,7 +692,8 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
   uint32_t slab = (uint32_t)c->adj_slab;
   if (slab == 0) {
-    const uint64_t target_slabs = std::max<uint64_t>(32, (128 + p.ncc - 1) / p.ncc);
+    // (float32 storage has half the column chunks per row: aim for the same ~1024 workgroups the float64 matrix gets at C2)
+    const uint64_t target_slabs = std::max<uint64_t>(32, ((c->f32 ? 1024 : 128) + p.ncc - 1) / p.ncc);
     const uint64_t slab_min = p.ncc >= 8 ? 128 : 32;
     uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
     slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, slab_min), ADJ_MAX_SLAB);
@@ -674,7 +726,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
 static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, const double* coef_src = nullptr) {
   AdjP p;
   memset(&p, 0, sizeof(p));
-  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n;
+  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.nv2 = p.ld2; p.n = (uint32_t)c->n;
   p.accel = io.accel; p.coef = io.coef; p.mode = 0; p.tau = io.tau;
   p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
   const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
@@ -833,9 +885,26 @@ struct FusedShape { int ppt, team, pipe; };
 static FusedShape fused_shape(fh_ctx* c) {
   FusedShape none = {0, 0, 0};
   if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ld % 2 || c->n == 0) return none;
-  const uint64_t pieces = round_up(c->n, 16) / 2;    // 16-byte pieces per row that hold data (the row stride c->ld may be padded)
-  if (pieces > c->ld / 2) return none;
+  // 16-byte pieces per row that hold data (the row stride c->ld may be padded): 2 columns each, 4 in float32 storage
+  const uint64_t pieces = c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2;
+  if (pieces > c->ld / (c->f32 ? 4 : 2)) return none;
   FusedShape sh = none;
+  if (c->f32) {
+    // float32 storage: the same byte rule (a member's piece of a row is 5..8 pieces per lane = 20-32 KiB per workgroup per
+    // row), i.e. twice the columns per team size: n <= 8192 one member, then 2 / 4 / 8 / 16 members up to n = 131072.  A piece
+    // carries four columns, so the x and g1 slices cost twice the registers per piece: from 5 pieces on the x slice lives in
+    // LDS and 3-4 row buffers rotate (launch_fused_f32), which hipcc allocates without spilling.
+    for (int team = 1; team <= 16; team *= 2) {
+      if (pieces > (uint64_t)team * FH_WG * 8) continue;
+      int ppt = (int)((pieces + (uint64_t)team * FH_WG - 1) / ((uint64_t)team * FH_WG));
+      if (ppt == 3) ppt = 4;
+      if (team > 1 && ppt < 5) ppt = 5;          // (cannot happen: pieces > (team/2)*256*8 already means ppt >= 5)
+      sh = {ppt, team, 1};
+      break;
+    }
+    if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;
+    return sh;
+  }
   if (pieces <= (uint64_t)1 * FH_WG * 8 && !(c->fused_variant & 8)) {
     int ppt = (int)((pieces + FH_WG - 1) / FH_WG);                       // n <= 4096: a workgroup owns whole rows, 256 "teams" of one
     if (ppt == 3) ppt = 4;
@@ -876,6 +945,23 @@ static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) 
   // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
   k_fused_dense<PPT, 1, PIPE, TEAM, XLDS, NBO><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
+// float32-storage twin (shapes: fused_shape); from 5 pieces per lane the x slice lives in LDS and 4 (5-6 pieces) or 3 (7-8
+// pieces) row buffers rotate, posting one row ahead -- the spill-free combinations (-Rpass-analysis=kernel-resource-usage)
+template <int PPT, int TEAM>
+static void launch_fused_f32(fh_ctx* c, const FusedP& p, unsigned grid) {
+  constexpr int XL = PPT >= 5 ? 1 : 0;
+  constexpr int NB = XL ? (PPT <= 6 ? 4 : 3) : 0;
+  k_fused_dense<PPT, 1, 1, TEAM, XL, NB, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+}
+template <int TEAM>
+static void launch_fused_f32_ppt(fh_ctx* c, const FusedP& p, unsigned grid, int ppt) {
+  switch (ppt) {
+    case 5: launch_fused_f32<5, TEAM>(c, p, grid); break;
+    case 6: launch_fused_f32<6, TEAM>(c, p, grid); break;
+    case 7: launch_fused_f32<7, TEAM>(c, p, grid); break;
+    default: launch_fused_f32<8, TEAM>(c, p, grid); break;
+  }
+}
 
 // operands of one fused launch; fh_step takes them from the solver state, fh_init / fh_gradient_at pass their own
 struct FusedIO {
@@ -894,7 +980,10 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const FusedShape sh = fused_shape(c);
   if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 262144 and a scalar-separable prox)");
   FusedP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.A = c->A; p.ld = c->ld; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
+  p.ldp = (uint32_t)(c->ld / (c->f32 ? 4 : 2));
+  p.nv2 = p.ld2 * (c->f32 ? 2u : 1u);
   p.nteams = (uint32_t)(c->ncu / sh.team);
   // few rows: fewer teams (at least FUSED_MIN_ROWS rows each when possible, and a multiple of 8 teams so that the members of
   // a team stay on one XCD): a smaller grid barrier and fewer g1 partials to sum in the epilogue
@@ -910,7 +999,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
   const unsigned grid = p.nteams * sh.team;
   const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);     // (32 members: four 64-byte lines per row)   // whole 64-byte lines; + one line per team for the restart dot
-  const size_t gpart_elems = (size_t)p.nteams * p.ld2 * 2;
+  const size_t gpart_elems = (size_t)p.nteams * p.nv2 * 2;
   FH_TRY(ensure_ws(c, (gpart_elems + (size_t)grid * 16) * sizeof(double)));
   p.gpart = c->ws; p.red = p.gpart + gpart_elems;
   if (2 * slots_elems * sizeof(double) > c->slotbuf_bytes) {
@@ -938,7 +1027,19 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
     c->slots_parity ^= 1;
   }
-  if (sh.team == 1) {
+  if (c->f32) {
+    if (sh.team == 1) {
+      switch (sh.ppt) {
+        case 1: launch_fused_f32<1, 1>(c, p, grid); break;
+        case 2: launch_fused_f32<2, 1>(c, p, grid); break;
+        case 4: launch_fused_f32<4, 1>(c, p, grid); break;
+        default: launch_fused_f32_ppt<1>(c, p, grid, sh.ppt); break;
+      }
+    } else if (sh.team == 2) launch_fused_f32_ppt<2>(c, p, grid, sh.ppt);
+    else if (sh.team == 4) launch_fused_f32_ppt<4>(c, p, grid, sh.ppt);
+    else if (sh.team == 8) launch_fused_f32_ppt<8>(c, p, grid, sh.ppt);
+    else launch_fused_f32_ppt<16>(c, p, grid, sh.ppt);
+  } else if (sh.team == 1) {
     switch (sh.ppt) {
       case 1: launch_fused_p<1, 1, 1>(c, p, grid, io.kind); break;
       case 2: launch_fused_p<2, 1, 1>(c, p, grid, io.kind); break;
@@ -1255,6 +1356,8 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
     NCCL_TRY(g_rccl.GroupStart());
     NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
     NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    // the timeout word too: every rank then sees the same verdict, so all of them drop to the two-launch path together
+    NCCL_TRY(g_rccl.AllReduce(c->dscal + 15, c->dscal + 15, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
     NCCL_TRY(g_rccl.GroupEnd());
     t_end(c, FH_K_COMM);
     AdjIO io;
@@ -1308,6 +1411,7 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
     NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
     NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
     NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ_ADJ, c->dscal + FH_S_FSQ_ADJ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->dscal + 15, c->dscal + 15, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));   // shared timeout verdict
     NCCL_TRY(g_rccl.GroupEnd());
     t_end(c, FH_K_COMM);
     AdjIO io;
@@ -1434,7 +1538,7 @@ extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint6
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "stream-read ceiling needs a dense matrix");
   if (reps < 1) reps = 1;
   // persistent workgroups, 1 per CU by default (FH_TUNE_FWD_GRID_CAP overrides), two register buffers of 16 nt loads per lane
-  const uint64_t npieces = c->mp * (c->ld / 2);
+  const uint64_t npieces = c->mp * (c->ld / (c->f32 ? 4 : 2));
   const unsigned grid = (unsigned)(c->fwd_cap > 0 ? c->fwd_cap : (c->ncu > 0 ? c->ncu : 256));
   double* sink = c->dscal + FH_NSCALARS + 2;
   k_stream_probe<16, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->A, npieces, sink);   // warm-up

@@ -24,12 +24,13 @@
 
 struct FwdP {
   const double* A;
-  uint64_t ld;          // doubles per device row
-  uint32_t ld2;         // ld / 2  (16-byte pieces per row)
+  uint64_t ld;          // elements per device row
+  uint32_t ld2;         // 16-byte pieces per device row (ld / 2 for float64 storage, ld / 4 for float32 storage)
+  uint32_t nv2;         // double pairs per n-side vector (= ld / 2)
   uint32_t n;           // logical columns
   uint32_t m;           // logical rows (padding rows carry no loss term)
   uint32_t nrg;         // row groups = mp / R
-  uint32_t nchunks;     // ceil(ld2 / 256)
+  uint32_t nchunks;     // ceil(nv2 / 256)
   const double* x0; const double* g0; const double* xacc0;
   double* xhat; double* xp;
   const double* b; double* z;
@@ -55,8 +56,10 @@ __device__ __forceinline__ d2 xprox_pair(const FwdP& p, uint32_t c, double level
   return xv;
 }
 
-template <int R, int NT, int KIND>
+template <int R, int NT, int KIND, int F32 = 0>
 __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
+  typedef typename PieceOf<F32>::type PT;
+  constexpr int XD = xd2<F32>();
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 16];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
     for (uint32_t chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
       const uint32_t c = chunk * FH_WG + tid;
       double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax, rdot
-      if (c < p.ld2) {
+      if (c < p.nv2) {
         const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
         const d2 g0v = reinterpret_cast<const d2*>(p.g0)[c];
         d2 xav = {0.0, 0.0};
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
   double fpart = 0.0;
   const uint32_t ntrip = (p.ld2 + 2 * FH_WG - 1) / (2 * FH_WG);
   for (uint32_t rg = blockIdx.x; rg < p.nrg; rg += gridDim.x) {
-    const d2* Ab = reinterpret_cast<const d2*>(p.A + (uint64_t)rg * R * p.ld);
+    const PT* Ab = reinterpret_cast<const PT*>(p.A) + (uint64_t)rg * R * p.ld2;
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -120,25 +123,23 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
       const uint32_t c1 = c0 + FH_WG;
       const bool ok0 = c0 < p.ld2, ok1 = c1 < p.ld2;
       const uint32_t k0 = ok0 ? c0 : 0u, k1 = ok1 ? c1 : 0u;   // clamp: in-bounds redundant loads
-      d2 a0[R], a1[R];
+      PT a0[R], a1[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) a0[r] = load_stream<NT>(Ab + (uint64_t)r * p.ld2 + k0);
 #pragma unroll
       for (int r = 0; r < R; ++r) a1[r] = load_stream<NT>(Ab + (uint64_t)r * p.ld2 + k1);
-      d2 x0v = xprox_pair<KIND>(p, k0, level);
-      d2 x1v = xprox_pair<KIND>(p, k1, level);
-      if (!ok0) x0v = (d2){0.0, 0.0};
-      if (!ok1) x1v = (d2){0.0, 0.0};
+      d2 x0v[XD], x1v[XD];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        acc[r] = fma(a0[r].x, x0v.x, acc[r]);
-        acc[r] = fma(a0[r].y, x0v.y, acc[r]);
+      for (int e = 0; e < XD; ++e) {
+        x0v[e] = xprox_pair<KIND>(p, k0 * XD + e, level);
+        x1v[e] = xprox_pair<KIND>(p, k1 * XD + e, level);
+        if (!ok0) x0v[e] = (d2){0.0, 0.0};
+        if (!ok1) x1v[e] = (d2){0.0, 0.0};
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        acc[r] = fma(a1[r].x, x1v.x, acc[r]);
-        acc[r] = fma(a1[r].y, x1v.y, acc[r]);
-      }
+      for (int r = 0; r < R; ++r) acc[r] = piece_dot(a0[r], x0v, acc[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = piece_dot(a1[r], x1v, acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
 struct AdjP {
   const double* A;
   uint64_t ld;
-  uint32_t ld2;
+  uint32_t ld2;         // 16-byte pieces per device row
+  uint32_t nv2;         // double pairs per n-side vector
   uint32_t n;
   uint32_t mp;          // padded rows
   uint32_t m;           // logical rows
@@ -234,8 +236,10 @@ __device__ __forceinline__ double bb_element(const AdjP& p, double g1, double x0
   return x1;
 }
 
-template <int CPT, int NT>
+template <int CPT, int NT, int F32 = 0>
 __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
+  typedef typename PieceOf<F32>::type PT;
+  constexpr int XD = xd2<F32>();
   __shared__ __attribute__((aligned(16))) double s_r[ADJ_MAX_SLAB];
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -257,28 +261,28 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 
   // ---- stream the slab: per-column accumulators, rows walked top to bottom ------------------------
   uint32_t col[CPT];
-  d2 acc[CPT];
+  d2 acc[CPT][XD];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
     col[j] = min(cc * (FH_WG * CPT) + j * FH_WG + tid, p.ld2 - 1u);   // clamp: redundant but in-bounds
-    acc[j] = (d2){0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < XD; ++e) acc[j][e] = (d2){0.0, 0.0};
   }
-  const d2* Ab = reinterpret_cast<const d2*>(p.A) + (uint64_t)row0 * p.ld2;
+  const PT* Ab = reinterpret_cast<const PT*>(p.A) + (uint64_t)row0 * p.ld2;
 #pragma unroll 4
   for (uint32_t i = 0; i < rows; ++i) {
     const double rv = s_r[i];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const d2 a = load_stream<NT>(Ab + col[j]);
-      acc[j].x = fma(a.x, rv, acc[j].x);
-      acc[j].y = fma(a.y, rv, acc[j].y);
-    }
+    for (int j = 0; j < CPT; ++j) piece_axpy(load_stream<NT>(Ab + col[j]), rv, acc[j]);
     Ab += p.ld2;
   }
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
     const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
-    if (c < p.ld2) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)slab * p.ld2 + c, acc[j]);
+    if (c < p.ld2) {
+#pragma unroll
+      for (int e = 0; e < XD; ++e) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)slab * p.nv2 + c * XD + e, acc[j][e]);
+    }
   }
   if (cc == 0) {
     double v[1] = {fs};
@@ -292,13 +296,14 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 
   double v[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) {
-    const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
-    if (c >= p.ld2) continue;
+  for (int j = 0; j < CPT * XD; ++j) {
+    const uint32_t piece = cc * (FH_WG * CPT) + (j / XD) * FH_WG + tid;
+    if (piece >= p.ld2) continue;
+    const uint32_t c = piece * XD + (j % XD);                      // double-pair index into the n-side vectors
     const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
     d2 g = {0.0, 0.0};
 #pragma unroll 16
-    for (uint32_t s = 0; s < p.nslab; ++s) g += load_partial2(gp + (uint64_t)s * p.ld2);
+    for (uint32_t s = 0; s < p.nslab; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
       const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
@@ -383,18 +388,39 @@ __global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t
 }
 
 // ---- utility kernels ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FH_WG) void k_gen_matrix(double* A, uint64_t ld, uint32_t ld2, uint32_t m, uint32_t mp,
+template <int F32>
+__global__ __launch_bounds__(FH_WG) void k_gen_matrix(double* A, uint32_t ld2, uint32_t m, uint32_t mp,
                                                       uint32_t n, uint64_t row0, uint64_t key, double coef) {
+  typedef typename PieceOf<F32>::type PT;
+  constexpr uint32_t E = F32 ? 4u : 2u;                         // columns per 16-byte piece
   const uint64_t total = (uint64_t)mp * ld2;
   for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < total; t += (uint64_t)gridDim.x * FH_WG) {
     const uint32_t row = (uint32_t)(t / ld2), c = (uint32_t)(t % ld2);
-    d2 v = {0.0, 0.0};
+    double e[4] = {0.0, 0.0, 0.0, 0.0};
     if (row < m) {
       const uint64_t base = (row0 + row) * (uint64_t)n;
-      if (2u * c < n) v.x = fh_ihall(key, base + 2u * c, coef);
-      if (2u * c + 1u < n) v.y = fh_ihall(key, base + 2u * c + 1u, coef);
+#pragma unroll
+      for (uint32_t k = 0; k < E; ++k)
+        if (E * c + k < n) e[k] = fh_ihall(key, base + E * c + k, coef);
     }
-    reinterpret_cast<d2*>(A)[t] = v;
+    PT v;
+    if constexpr (F32) { v.x = (float)e[0]; v.y = (float)e[1]; v.z = (float)e[2]; v.w = (float)e[3]; }   // round to nearest even, as ndarray.astype(float32)
+    else { v.x = e[0]; v.y = e[1]; }
+    reinterpret_cast<PT*>(A)[t] = v;
+  }
+}
+
+// float64 rows <-> float32 storage (fh_set_matrix / fh_get_matrix_rows in float32-storage mode), `rows` x `n` elements
+__global__ __launch_bounds__(FH_WG) void k_rows_to_f32(const double* src, uint64_t src_ld, float* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
+  for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < (uint64_t)rows * n; t += (uint64_t)gridDim.x * FH_WG) {
+    const uint64_t r = t / n, c = t % n;
+    dst[r * dst_ld + c] = (float)src[r * src_ld + c];
+  }
+}
+__global__ __launch_bounds__(FH_WG) void k_rows_from_f32(const float* src, uint64_t src_ld, double* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
+  for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < (uint64_t)rows * n; t += (uint64_t)gridDim.x * FH_WG) {
+    const uint64_t r = t / n, c = t % n;
+    dst[r * dst_ld + c] = (double)src[r * src_ld + c];
   }
 }
 

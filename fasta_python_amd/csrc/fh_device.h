@@ -13,6 +13,36 @@
 #include <stdint.h>
 
 typedef double d2 __attribute__((ext_vector_type(2)));   // one 16-byte global access
+typedef float f4 __attribute__((ext_vector_type(4)));    // one 16-byte piece of a float32-storage matrix: four columns
+
+// ---- storage type of A ---------------------------------------------------------------------------------------------------
+// A "piece" is one aligned 16-byte access to a row of A: two float64 columns (F32 = 0) or four float32 columns (F32 = 1, the
+// opt-in storage mode: half the bytes per pass; every vector, every accumulation and every scalar stays float64).  The matching
+// stretch of an n-side vector is XD2 = 1 or 2 double pairs.
+template <int F32> struct PieceOf { typedef d2 type; };
+template <> struct PieceOf<1> { typedef f4 type; };
+template <int F32> __device__ __forceinline__ constexpr int xd2() { return F32 ? 2 : 1; }
+
+__device__ __forceinline__ double piece_dot(d2 a, const d2 (&x)[1], double acc) {
+  acc = fma(a.x, x[0].x, acc);
+  return fma(a.y, x[0].y, acc);
+}
+__device__ __forceinline__ double piece_dot(f4 a, const d2 (&x)[2], double acc) {
+  acc = fma((double)a.x, x[0].x, acc);
+  acc = fma((double)a.y, x[0].y, acc);
+  acc = fma((double)a.z, x[1].x, acc);
+  return fma((double)a.w, x[1].y, acc);
+}
+__device__ __forceinline__ void piece_axpy(d2 a, double r, d2 (&g)[1]) {
+  g[0].x = fma(a.x, r, g[0].x);
+  g[0].y = fma(a.y, r, g[0].y);
+}
+__device__ __forceinline__ void piece_axpy(f4 a, double r, d2 (&g)[2]) {
+  g[0].x = fma((double)a.x, r, g[0].x);
+  g[0].y = fma((double)a.y, r, g[0].y);
+  g[1].x = fma((double)a.z, r, g[1].x);
+  g[1].y = fma((double)a.w, r, g[1].y);
+}
 
 #define FH_WG 256
 
@@ -189,6 +219,11 @@ __device__ __forceinline__ bool publish_partials(double* slot, const double (&v)
 // 16-byte streaming load of A.  NT=1 marks it non-temporal (read-once stream; keeps x0/g0 in L2).
 template <int NT>
 __device__ __forceinline__ d2 load_stream(const d2* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <int NT>
+__device__ __forceinline__ f4 load_stream(const f4* p) {
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
 }

@@ -80,7 +80,8 @@ __device__ __forceinline__ double ft_wave_sum(double v) {       // every lane ge
 struct FusedP {
   const double* A;
   uint64_t ld;
-  uint32_t ld2, n, m, mp;   // ld2: 16-byte pieces of a row that hold data (round_up(n,16)/2 <= TEAM*256*PPT); ld: row stride of A in doubles
+  uint32_t ld2, n, m, mp;   // ld2: 16-byte pieces of a row that hold data (<= TEAM*256*PPT); ld: row stride of A in elements
+  uint32_t ldp, nv2;        // ldp: row stride of A in 16-byte pieces; nv2: double pairs per n-side vector (ld2 x 1 or x 2, see PieceOf)
   uint32_t nteams, rows_per_team;
   const double* x0; const double* g0;
   double* xhat; double* xp;
@@ -114,9 +115,11 @@ __device__ __forceinline__ double ft_sentinel() { return __hiloint2double((int)F
 // registers, two hot row buffers + the g1 slice + the x slice exceed what hipcc can keep out of scratch (300-600 spilled
 // registers, 2x slower); with it in LDS and NBO = 3-4 row buffers the loop compiles without spills and streams at the rate of
 // the narrow shapes (n = 131072: 5.36 -> 7.16 TB/s, profiles/r02_fused_wide.txt).
-template <int PPT, int NT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0>      // NBO: number of row buffers (0 = the schedule's default)
+template <int PPT, int NT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0, int F32 = 0>   // NBO: number of row buffers (0 = the schedule's default); F32: float32-storage A
 __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
-  __shared__ __attribute__((aligned(16))) d2 s_x[XLDS ? PPT * FH_WG : 1];
+  typedef typename PieceOf<F32>::type PT;
+  constexpr int XD = xd2<F32>();                  // double pairs of x / g1 per 16-byte piece of A
+  __shared__ __attribute__((aligned(16))) d2 s_x[XLDS ? PPT * XD * FH_WG : 1];
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_part2[2][4];  // TEAM == 1: wave partials, double-buffered by trip parity
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
@@ -132,40 +135,44 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   const double level = (kind == PX_LINF || kind == PX_L1BALL) ? *p.px.level : 0.0;
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
-  d2 xq[XLDS ? 1 : PPT];
+  d2 xq[XLDS ? 1 : PPT][XD];
   double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax (team 0 only); [6]: restart dot (every team)
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const uint32_t c = c0 + k * FH_WG;
     const uint32_t cl = min(c, p.ld2 - 1u);          // lanes past the row's last piece re-read it (results masked out)
-    const d2 x0v = reinterpret_cast<const d2*>(p.x0)[cl];
-    const d2 g0v = reinterpret_cast<const d2*>(p.g0)[cl];
-    d2 xav = {0.0, 0.0};
-    if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[cl];
-    d2 xh, xp;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const bool valid = (2u * c + e) < p.n;
-      double xhe = fwd_point(x0v[e], g0v[e], p.tau);
-      double xpe = prox_scalar_rt(kind, xhe, p.px, level);
-      if (!valid) { xhe = 0.0; xpe = 0.0; }
-      xh[e] = xhe; xp[e] = xpe;
-      if (valid) v[6] = fma(sub_nofma(x0v[e], xpe), sub_nofma(xpe, xav[e]), v[6]);
-      if (valid && team == 0) {
-        const double dx = sub_nofma(xpe, x0v[e]);
-        const double dh = sub_nofma(xpe, xhe);
-        v[0] = fma(dx, g0v[e], v[0]);
-        v[1] = fma(dx, dx, v[1]);
-        v[2] = fma(dh, dh, v[2]);
-        v[3] = fma(g0v[e], g0v[e], v[3]);
-        v[4] += fabs(xpe);
-        v[5] = fmax(v[5], fabs(xpe));
+    for (int h = 0; h < XD; ++h) {
+      const uint32_t ci = cl * XD + h, cr = c * XD + h;   // double-pair index: clamped (loads) / real (validity, stores)
+      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[ci];
+      const d2 g0v = reinterpret_cast<const d2*>(p.g0)[ci];
+      d2 xav = {0.0, 0.0};
+      if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[ci];
+      d2 xh, xp;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool valid = (2u * cr + e) < p.n;
+        double xhe = fwd_point(x0v[e], g0v[e], p.tau);
+        double xpe = prox_scalar_rt(kind, xhe, p.px, level);
+        if (!valid) { xhe = 0.0; xpe = 0.0; }
+        xh[e] = xhe; xp[e] = xpe;
+        if (valid) v[6] = fma(sub_nofma(x0v[e], xpe), sub_nofma(xpe, xav[e]), v[6]);
+        if (valid && team == 0) {
+          const double dx = sub_nofma(xpe, x0v[e]);
+          const double dh = sub_nofma(xpe, xhe);
+          v[0] = fma(dx, g0v[e], v[0]);
+          v[1] = fma(dx, dx, v[1]);
+          v[2] = fma(dh, dh, v[2]);
+          v[3] = fma(g0v[e], g0v[e], v[3]);
+          v[4] += fabs(xpe);
+          v[5] = fmax(v[5], fabs(xpe));
+        }
       }
-    }
-    if (XLDS) s_x[k * FH_WG + tid] = xp; else xq[XLDS ? 0 : k] = xp;      // (each lane only ever reads back its own entries)
-    if (team == 0 && c < p.ld2) {   // write-through: other workgroups read these back after the grid barrier
-      store_partial2(reinterpret_cast<d2*>(p.xhat) + c, xh);
-      store_partial2(reinterpret_cast<d2*>(p.xp) + c, xp);
+      if (XLDS) s_x[(k * XD + h) * FH_WG + tid] = xp; else xq[XLDS ? 0 : k][h] = xp;      // (each lane only ever reads back its own entries)
+      if (team == 0 && c < p.ld2) {   // write-through: other workgroups read these back after the grid barrier
+        store_partial2(reinterpret_cast<d2*>(p.xhat) + cr, xh);
+        store_partial2(reinterpret_cast<d2*>(p.xp) + cr, xp);
+      }
     }
   }
 
@@ -181,9 +188,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
                                  : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
   const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
   auto grow = [&](uint32_t r) { return row_base + r * row_step; };
-  d2 ga[PPT];
+  d2 ga[PPT][XD];
 #pragma unroll
-  for (int k = 0; k < PPT; ++k) ga[k] = (d2){0.0, 0.0};
+  for (int k = 0; k < PPT; ++k)
+#pragma unroll
+    for (int h = 0; h < XD; ++h) ga[k][h] = (d2){0.0, 0.0};
   double fs = 0.0, fsa = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
 #ifdef FT_PROFILE
@@ -197,8 +206,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   uint32_t pc[PPT];                                  // this lane's piece indices, clamped to the row's last piece
 #pragma unroll
   for (int k = 0; k < PPT; ++k) pc[k] = min(c0 + k * FH_WG, p.ld2 - 1u);
-  auto load_row = [&](d2 (&buf)[PPT], uint32_t r) {
-    const d2* src = reinterpret_cast<const d2*>(p.A) + (uint64_t)grow(r) * (p.ld / 2);
+  auto load_row = [&](PT (&buf)[PPT], uint32_t r) {
+    const PT* src = reinterpret_cast<const PT*>(p.A) + (uint64_t)grow(r) * p.ldp;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + pc[k]);
   };
@@ -264,22 +273,20 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       store_partial(p.slots_next + at, ft_sentinel());      // fire and forget: read by the launch after this one
     }
   };
-  auto dot_row = [&](const d2 (&buf)[PPT]) -> double {
+  auto dot_row = [&](const PT (&buf)[PPT]) -> double {
     double part = 0.0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-      const d2 xv = XLDS ? s_x[k * FH_WG + tid] : xq[XLDS ? 0 : k];
-      part = fma(buf[k].x, xv.x, part);
-      part = fma(buf[k].y, xv.y, part);
+      d2 xv[XD];
+#pragma unroll
+      for (int h = 0; h < XD; ++h) xv[h] = XLDS ? s_x[(k * XD + h) * FH_WG + tid] : xq[XLDS ? 0 : k][h];
+      part = piece_dot(buf[k], xv, part);
     }
     return ft_wave_sum(part);
   };
-  auto update_row = [&](const d2 (&buf)[PPT], double rv) {
+  auto update_row = [&](const PT (&buf)[PPT], double rv) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      ga[k].x = fma(buf[k].x, rv, ga[k].x);
-      ga[k].y = fma(buf[k].y, rv, ga[k].y);
-    }
+    for (int k = 0; k < PPT; ++k) piece_axpy(buf[k], rv, ga[k]);
   };
   // ---------------- FISTA: every team needs this step's restart dot before its first row (the gradient is taken at the
   // extrapolated z): the members exchange their slice sums through the team's extra slot line, summed in member order
@@ -312,8 +319,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // ---- a workgroup owns whole rows (n <= 4096): no exchange at all.  One barrier per trip: the wave partials are
     // double-buffered by trip parity, every thread sums them and evaluates the row's gradient factor itself.
     if (r_begin < r_end) {
-      constexpr int NB = PPT >= 8 ? 5 : 6;
-      d2 B[NB][PPT];
+      constexpr int NB = NBO ? NBO : (PPT >= 8 ? 5 : 6);
+      PT B[NB][PPT];
       const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
 #pragma unroll
       for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   } else if constexpr (!PIPE) {
     // ---- exchange in line: prefetch r+NB-1 | dot r | exchange r | update r  (NB-1 rows in flight during the exchange)
-    auto process_row = [&](d2 (&buf)[PPT], uint32_t r, d2 (&nbuf)[PPT], uint32_t nr) {   // uniform over the workgroup; r >= r_end: phantom
+    auto process_row = [&](PT (&buf)[PPT], uint32_t r, PT (&nbuf)[PPT], uint32_t nr) {   // uniform over the workgroup; r >= r_end: phantom
       const bool live = r < r_end;
       const uint32_t gr = grow(min(r, r_last));
       load_row(nbuf, min(nr, r_last));
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       // pieces are all the registers hold next to the x slice; with the slice in LDS (XLDS) there is room for four or five.
       // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
       constexpr int NB = NBO ? NBO : 3;
-      d2 B[NB][PPT];
+      PT B[NB][PPT];
       const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
 #pragma unroll
       for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     constexpr int D = PIPE;                                        // rows between a post and its poll
     constexpr int NB = NBO ? NBO : (PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6));     // D+1 rows are held, NB-1-D rows prefetch
     static_assert(NB >= D + 2, "need at least one prefetching buffer");
-    d2 B[NB][PPT];
+    PT B[NB][PPT];
     const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
@@ -483,7 +490,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // ---------------- publish this member's slice partial, loss partial and (team 0) n-side partials -------------
 #pragma unroll
   for (int k = 0; k < PPT; ++k)
-    if (c0 + k * FH_WG < p.ld2) store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.ld2 + c0 + k * FH_WG, ga[k]);
+    if (c0 + k * FH_WG < p.ld2) {
+#pragma unroll
+      for (int h = 0; h < XD; ++h)
+        store_partial2(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2 + (c0 + k * FH_WG) * XD + h, ga[k][h]);
+    }
   {
     double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], fsa};
     block_reduce<8>(w, s_scr, 6);
@@ -513,14 +524,14 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   AdjP e;                                            // reuse K-adj's per-element epilogue
   e.accel = p.accel; e.coef = coef; e.tau = p.tau;
   double u[5] = {0, 0, 0, 0, 0};                     // dxdg, dg2, xh2, gsum, gmax
-  const uint32_t share = (p.ld2 + gridDim.x - 1) / gridDim.x;
+  const uint32_t share = (p.nv2 + gridDim.x - 1) / gridDim.x;
   for (uint32_t t = tid; t < share; t += FH_WG) {
-    const uint32_t c = blockIdx.x * share + t;
-    if (c >= p.ld2) continue;
+    const uint32_t c = blockIdx.x * share + t;       // double-pair index into the n-side vectors
+    if (c >= p.nv2) continue;
     const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
     d2 g = {0.0, 0.0};
 #pragma unroll 8
-    for (uint32_t s = 0; s < p.nteams; ++s) g += load_partial2(gp + (uint64_t)s * p.ld2);
+    for (uint32_t s = 0; s < p.nteams; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
       // xhat / xp were written by team 0 with plain stores earlier in THIS launch: read them back through sc1

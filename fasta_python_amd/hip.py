@@ -23,6 +23,8 @@ K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT) = range(10)
 UNIQUE_ID_BYTES = 128
+DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
+STORAGE = {"f64": DTYPE_F64, "f32": DTYPE_F32_STORAGE}
 
 _u64, _i32, _dbl = C.c_uint64, C.c_int, C.c_double
 _ctx = C.c_void_p
@@ -33,6 +35,7 @@ SIGNATURES = {
     "fh_last_error": (C.c_char_p, []),
     "fh_device_count": (_i32, [C.POINTER(_i32)]),
     "fh_create": (_i32, [_i32, C.POINTER(_ctx)]),
+    "fh_create_ex": (_i32, [_i32, C.POINTER(_i32), _i32, C.POINTER(_ctx)]),
     "fh_destroy": (_i32, [_ctx]),
     "fh_sync": (_i32, [_ctx]),
     "fh_set_tuning": (_i32, [_ctx, _i32, C.c_longlong]),
@@ -118,11 +121,20 @@ def comm_unique_id():
 class HipContext:
     """One device context (stream, device-resident A, vectors, workspace).  Not thread-safe."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, storage="f64"):
+        """storage: "f64" (default) or "f32" -- the device copy of a dense A in float32 (opt-in throughput mode; vectors,
+        accumulation and scalars stay float64)."""
         self.lib = load_library()
         self._h = _ctx()
-        _check(self.lib, self.lib.fh_create(int(device), C.byref(self._h)))
+        if storage not in STORAGE:
+            raise ValueError('storage must be "f64" or "f32"')
+        if storage == "f64":
+            _check(self.lib, self.lib.fh_create(int(device), C.byref(self._h)))
+        else:
+            ids = (_i32 * 1)(int(device))
+            _check(self.lib, self.lib.fh_create_ex(1, ids, STORAGE[storage], C.byref(self._h)))
         self.device = int(device)
+        self.storage = storage
         self._scal = np.zeros(NSCALARS)
         self._scal_p = self._scal.ctypes.data_as(_pd)
         self.sharded = False            # True once a multi-rank communicator is attached (comm_init)

@@ -109,8 +109,8 @@ LinearOperator = LinearMap      # name the reference's examples import (sparse_l
 class _DeviceMap(LinearMap):
     """A LinearMap whose operator lives in a HipContext; `fasta()` runs the fused device loop on it."""
 
-    def __init__(self, Vshape, Wshape, device):
-        self.ctx = hip.HipContext(device)
+    def __init__(self, Vshape, Wshape, device, storage="f64"):
+        self.ctx = hip.HipContext(device, storage)
         self.device = device
         LinearMap.__init__(self, self._apply_fwd, self._apply_adj, Vshape, Wshape)
 
@@ -162,14 +162,18 @@ class DenseMatrixMap(_DeviceMap):
     ranks (one process per GPU); the default is the whole matrix on one GPU.
     """
 
-    def __init__(self, A=None, device=0, tuning=None, _defer=False):
+    def __init__(self, A=None, device=0, tuning=None, _defer=False, storage="f64"):
+        """storage="f32" (opt-in): keep the device copy of A in float32 -- half the bytes per pass, ~2x the iterations/s on
+        large matrices.  The solve is then the reference's solve on the ROUNDED matrix A.astype(float32) (all vectors and
+        arithmetic stay float64), so iterates differ from the float64-matrix run by the effect of that rounding."""
         self.rows = None
         self.shape = None
+        self.storage = storage
         if _defer:
-            _DeviceMap.__init__(self, (0,), (0,), device)
+            _DeviceMap.__init__(self, (0,), (0,), device, storage)
         else:
             assert A is not None and A.ndim == 2
-            _DeviceMap.__init__(self, (A.shape[1],), (A.shape[0],), device)
+            _DeviceMap.__init__(self, (A.shape[1],), (A.shape[0],), device, storage)
             self._tune(tuning)
             self.ctx.set_matrix(A)
             self.shape = tuple(A.shape)
@@ -179,10 +183,10 @@ class DenseMatrixMap(_DeviceMap):
             self.ctx.set_tuning(key, value)
 
     @classmethod
-    def synthetic(cls, m, n, seed, scale, row0=0, m_total=None, device=0, tuning=None):
+    def synthetic(cls, m, n, seed, scale, row0=0, m_total=None, device=0, tuning=None, storage="f64"):
         """Rows [row0, row0+m) of the counter-based synthetic matrix, generated in HBM."""
         from .synthetic import synth_coef
-        self = cls(_defer=True, device=device)
+        self = cls(_defer=True, device=device, storage=storage)
         self._tune(tuning)
         self.ctx.generate_matrix(m, n, row0, seed, synth_coef(scale))
         self.Vshape, self.Wshape = (n,), (m,)

@@ -95,6 +95,13 @@ enum fh_tuning_key {
 const char* fh_last_error(void);
 int fh_device_count(int* count);
 int fh_create(int device, fh_ctx** out);
+/* SURVEY.md 8(b) form: device list + storage type of A.  One process drives one GPU (row sharding = one context per process,
+ * fh_comm_init), so ndev must be 1.  dtype FH_DTYPE_F32_STORAGE keeps the device copy of A in float32 (rounded to nearest on
+ * upload / generation): half the bytes per pass; every vector, accumulation and scalar stays float64.  OPT-IN: the iterates
+ * are those of the reference run on the ROUNDED matrix, i.e. they differ from the float64-matrix run by the rounding of A
+ * (relative 6e-8 per entry; SURVEY.md section 7: <= 3e-7 on the iterates away from the chaotic regime).                  */
+enum fh_dtype { FH_DTYPE_F64 = 0, FH_DTYPE_F32_STORAGE = 1 };
+int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out);
 int fh_destroy(fh_ctx* ctx);
 int fh_sync(fh_ctx* ctx);
 int fh_set_tuning(fh_ctx* ctx, int key, long long value);
