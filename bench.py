@@ -207,9 +207,9 @@ def pmc_traffic(kernel_substr):
     for path in reversed(files):                       # newest summary that profiled this kernel
         with open(path) as fh:
             data = json.load(fh)
-        for name, rec in data["kernels"].items():
-            if kernel_substr in name:
-                return rec["traffic_bytes"], os.path.basename(path)
+        hits = [rec["traffic_bytes"] for name, rec in data["kernels"].items() if kernel_substr in name]
+        if hits:                                       # several instantiations (e.g. the float32-storage twin): the headline's is the largest
+            return max(hits), os.path.basename(path)
     return None, None
 
 

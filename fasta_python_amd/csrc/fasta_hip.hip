@@ -1118,7 +1118,8 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
 
 // z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, fused_pays()):
 // identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
-static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && fused_pays(c); }
+static bool cu_masked() { return getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"); }
+static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && fused_pays(c) && !cu_masked(); }
 // returns 0 and sets *ok = false when the launch reported a spin timeout (caller falls back to two launches)
 static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bool* ok) {
   const FusedIO fio = {x, x, c->xhat, c->P[c->pc ^ 1], z, g, FH_PROX_IDENTITY, 2};
@@ -1275,7 +1276,11 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // 3 = dense one-pass kernel available but NOT recommended: its launch has ~35-50 us of fixed cost (slot fill, n-side
   //     prologue, grid barrier, epilogue), which two short launches under one sync beat on a small matrix
   //     (profiles/r02_fused_crossover.txt: 512 x 1024 35.6 vs 34.9 us, 2048^2 46 vs 53 us, 1024 x 8192 60 vs 63 us, 4096^2 77 vs 76 us)
-  const int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
+  int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
+  // The dense one-pass kernel needs its whole grid (one workgroup per CU the device REPORTS) co-resident.  A CU mask hides
+  // CUs from the dispatcher without changing that count: say "unsupported" up front instead of running into the bounded-spin
+  // timeout on the first launch (the timeout stays as the safety net for partition modes this check cannot see).
+  if (ppt && (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))) ppt = 0;
   *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
   return 0;
 }

@@ -2,7 +2,7 @@
 # rocprofv3 passes over the default bench: kernel trace + stats, then HBM counters (separate passes,
 # MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots").  Usage: bash scripts/profile_bench.sh <tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
