@@ -84,6 +84,21 @@ def self_launch(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+class quiet_stdout:
+    """Park the C-level stdout (fd 1) on stderr for the duration: gloo announces its peers and RCCL prints a version banner
+    there, and the driver reads ONE JSON line from stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+
+
 class Group:
     """Rendezvous/barrier plumbing: torch.distributed over gloo when launched with >1 rank."""
 
@@ -99,16 +114,9 @@ class Group:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            # gloo announces its peers on the C-level stdout; the driver reads ONE JSON line there, so park fd 1 on stderr
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with quiet_stdout():
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
                 dist.barrier()
-            finally:
-                os.dup2(keep, 1)
-                os.close(keep)
             self.dist, self.torch = dist, torch
 
     def barrier(self):
@@ -405,8 +413,9 @@ def main(argv=None):
         A = fa.DenseMatrixMap.synthetic(rows, n, seed=0, scale=synthetic.lasso_scale(m_all, n), row0=grp.rank * rows,
                                         m_total=m_all, device=grp.local_rank, tuning=tuning, storage=storage or args.storage)
         if grp.world > 1 or grp.force:
-            uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
-            A.ctx.comm_init(grp.world, grp.rank, uid)
+            with quiet_stdout():                       # (RCCL's version banner goes to stdout)
+                uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
+                A.ctx.comm_init(grp.world, grp.rank, uid)
         return A
 
     A = shard(m_total)
