@@ -314,10 +314,10 @@ def sub_result(r, workload):
 
 
 def tv_bytes(P, accelerate):
-    """Algorithmic bytes per launch of the stencil kernels as executed: the gradient is never
-    materialised.  One-pass: reads x0 16 + z_cur 8 + b 8, writes xprox 16 + z_new 8 per pixel; with FISTA the iterate and
-    its image are kept as (prox output, previous prox output, coefficient): reads 2x16 + 2x8 + 8, writes 16 + 8."""
-    return {"fwd": 56 * P, "adj": (56 + (48 if accelerate else 0)) * P, "fused": (80 if accelerate else 56) * P}
+    """Algorithmic bytes per launch of the stencil kernels as executed: neither the gradient nor -- in the
+    one-pass kernel -- z is materialised.  One-pass: reads x0 16 + b 8, writes xprox 16 per pixel; with FISTA the iterate is
+    kept as (prox output, previous prox output, coefficient): reads 2 x 16 + 8, writes 16.  Two launches: 56 + 56 (+48 FISTA)."""
+    return {"fwd": 56 * P, "adj": (56 + (48 if accelerate else 0)) * P, "fused": (56 if accelerate else 40) * P}
 
 
 def run_tv(args, grp, steps, warmup, fused, accelerate):
@@ -331,6 +331,9 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
     M += 0.1 * np.random.standard_normal(M.shape)
     mu = 0.1
     A = fa.GradDivMap(M.shape, device=grp.local_rank)
+    for item in filter(None, args.tune.split(",")):
+        k, v = item.split("=")
+        A.ctx.set_tuning(int(k), int(v))
     try:
         loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
         solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=not accelerate, accelerate=accelerate,
@@ -342,7 +345,7 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
     P = side * side
     by = tv_bytes(P, accelerate)
     per = {"fasta_fwd(k_fwd_tv_step)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_tv_step)": t["k"]["adj"] + (by["adj"],),
-           ("fasta_step_accel(k_fused_tv_accel)" if accelerate else "fasta_step(k_fused_tv_step)"): t["k"]["fused"] + (by["fused"],)}
+           ("fasta_step_accel(k_tv_onepass<accel>)" if accelerate else "fasta_step(k_tv_onepass)"): t["k"]["fused"] + (by["fused"],)}
     dom, table = kernel_table(per)
     model_bytes = (steps * 136 + t["backtracks"] * 64) * P
     return {
@@ -367,7 +370,7 @@ def tv_line(args, r, accelerate):
         "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), {'FISTA' if accelerate else 'adaptive FBS'} with backtracking",
                    "backtracks_in_timed_steps": r["backtracks"], "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GB/s"] / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(("k_fused_tv_accel" if accelerate else "k_fused_tv_step") if "fused" in r["dominant"] else
+                     "traffic": pmc_traffic(("k_tv_onepass<0, 1" if accelerate else "k_tv_onepass<0, 0") if "k_tv_onepass" in r["dominant"] else
                                             ("k_fwd_tv_step" if "fwd" in r["dominant"] else "k_adj_tv_step"))[0] if side == 8192 else None,
                      "kernel": r["dominant"], "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "per_kernel": r["per_kernel"], "loop_GB/s_wallclock": r["loop_GB/s_wallclock"],

@@ -135,6 +135,11 @@ struct fh_ctx {
   int lb1 = 0, lb0 = 0;                 // best-quality iterate = nq(lb1) + lbc*(nq(lb1) - nq(lb0)), by reference
   double lbc = 0.0, lc = 0.0, lc_pending = 0.0;   // coefficient of the best iterate / of x0 / decided by the launch awaiting fh_commit
   uint64_t commits = 0;                 // fh_commit calls since fh_init
+  // z-free one-pass stencil kernels (k_tv_onepass, the default): they neither read nor write z, so after such a step is
+  // committed the stored image of x0 is stale; the two-launch kernels recompute it on demand (one plain div pass)
+  int tv_zfree = 1;                     // FH_TUNE_TV_ZFREE
+  bool tvz_pending = false;             // the latest launch was z-free (its z_new exists only inside the kernel)
+  bool zcur_stale = false;
   bool has_b = false;
   int loss_kind = LOSS_LSQ;
   // prox
@@ -156,7 +161,7 @@ struct fh_ctx {
   int nt_loads = 1;
   // stencil defaults measured on MI355X at 8192^2 (profiles/r01_tune_tv.txt): plain (not nt) accesses,
   // 8 rows in flight, 32 rows per workgroup for K-fwd and 128 for the read-only K-adj
-  int tv_u = 8;
+  int tv_u = 0;              // 0 = auto: 8 for the kernels that stream z, 2 / 4 for the z-free one-pass sweeps (profiles/r02_tune_tv.txt)
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
@@ -370,13 +375,15 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
     case FH_TUNE_NT_LOADS:
       c->nt_loads = value ? 1 : 0; return 0;
     case FH_TUNE_TV_U:
-      if (value != 2 && value != 4 && value != 8) return fail(FH_E_ARG, "TV_U must be 2, 4 or 8");
+      if (value != 0 && value != 2 && value != 4 && value != 8) return fail(FH_E_ARG, "TV_U must be 0 (auto), 2, 4 or 8");
       c->tv_u = (int)value; return 0;
     case FH_TUNE_TV_ROWS:
       if (value < 0 || value > 4096) return fail(FH_E_ARG, "TV_ROWS must be in [0,4096] (0 = auto)");
       c->tv_rows = (int)value; return 0;
     case FH_TUNE_TV_NT:
       c->tv_nt = value ? 1 : 0; return 0;
+    case FH_TUNE_TV_ZFREE:
+      c->tv_zfree = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_VARIANT:
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h); bits 9-10: wide-row candidate
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
@@ -540,6 +547,19 @@ static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
   }
 }
 
+static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
+                         double* xhat, double* xp, double* z, int sub_b);
+// z = div(x) into `z` (plain stencil pass; the scalar block is scratch afterwards)
+static int tv_image(fh_ctx* c, const double* x, double* z) { return launch_fwd_tv(c, 1, 0.0, x, nullptr, nullptr, nullptr, nullptr, z, 0); }
+// the two-launch stencil kernels read the stored image of x0: bring it up to date after z-free steps
+static int tv_refresh_zcur(fh_ctx* c) {
+  if (c->op != OP_STENCIL || !c->zcur_stale) return 0;
+  FH_TRY(tv_image(c, c->X[c->xi], c->Z[c->zc]));
+  c->zcur = c->Z[c->zc];
+  c->zcur_stale = false;
+  return 0;
+}
+
 // ---- lazily-kept stencil iterate (one-pass FISTA) ---------------------------------------------------
 static inline double* nq(fh_ctx* c, int i) { return i < 3 ? c->X[i] : c->P[i - 3]; }
 static inline double* mq(fh_ctx* c, int i) { return i < 2 ? c->Z[i] : c->ZX[0]; }
@@ -590,6 +610,10 @@ extern "C" int fh_get_vector(fh_ctx* c, int which, double* host, uint64_t len) {
   FH_TRY(use_device(c));
   if (c->lazy && (which == FH_VEC_X0 || which == FH_VEC_X1 || which == FH_VEC_BEST || which == FH_VEC_XPROX)) FH_TRY(lazy_vec(c, which, &d));
   if (c->lazy && which == FH_VEC_Z) d = mq(c, c->lzn);
+  if (c->op == OP_STENCIL && which == FH_VEC_Z && c->tvz_pending) {      // z1 = div(xprox) was never written: form it now
+    FH_TRY(tv_image(c, c->lazy ? nq(c, c->lqn) : c->P[c->pc ^ 1], c->zt));
+    d = c->zt;
+  }
   if (!d) return fail(FH_E_ARG, "unknown vector id %d", which);
   if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
   HIP_TRY(hipMemcpyAsync(host, d, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -804,8 +828,8 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
     if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fwd_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
-    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
+    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
+    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
 #undef TV_STEP
     t_end(c, FH_K_FWD);
     HIP_TRY(hipGetLastError());
@@ -844,8 +868,8 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
     p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
     t_begin(c, FH_K_ADJ);
 #define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 8) TV_STEP(8, 1); else TV_STEP(4, 1); }
-    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 8) TV_STEP(8, 0); else TV_STEP(4, 0); }
+    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
+    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
 #undef TV_STEP
     t_end(c, FH_K_ADJ);
     HIP_TRY(hipGetLastError());
@@ -1170,7 +1194,7 @@ static int check_ready(fh_ctx* c, bool need_b) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_init(fh_ctx* c, double* scalars) {
   FH_TRY(check_ready(c, true));
-  c->lazy = false; c->commits = 0;
+  c->lazy = false; c->commits = 0; c->tvz_pending = false; c->zcur_stale = false;
   double* x0 = c->X[c->xi];
   // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
   bool fused_done = false;
@@ -1231,6 +1255,8 @@ extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
 extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
   FH_TRY(not_lazy(c, "fh_fwd"));
+  FH_TRY(tv_refresh_zcur(c));
+  c->tvz_pending = false;
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
@@ -1256,6 +1282,8 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
 extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
   FH_TRY(not_lazy(c, "fh_fwd_adj"));
+  FH_TRY(tv_refresh_zcur(c));
+  c->tvz_pending = false;
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
   FH_TRY(reduce_fsq_over_ranks(c));
@@ -1304,8 +1332,8 @@ static int launch_fused_tv(fh_ctx* c, double tau) {
     if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fused_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-  if (c->tv_nt) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 8) TV_FUSED(8, 1); else TV_FUSED(4, 1); }
-  else { if (c->tv_u == 2) TV_FUSED(2, 0); else if (c->tv_u == 8) TV_FUSED(8, 0); else TV_FUSED(4, 0); }
+  if (c->tv_nt) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 4) TV_FUSED(4, 1); else TV_FUSED(8, 1); }
+  else { if (c->tv_u == 2) TV_FUSED(2, 0); else if (c->tv_u == 4) TV_FUSED(4, 0); else TV_FUSED(8, 0); }
 #undef TV_FUSED
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
@@ -1331,11 +1359,42 @@ static int launch_fused_tv_accel(fh_ctx* c, double tau, double coef, int restart
     if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_accel<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fused_tv_accel<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-  if (c->tv_nt) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 8) TV_ACCEL(8, 1); else TV_ACCEL(4, 1); }
-  else { if (c->tv_u == 2) TV_ACCEL(2, 0); else if (c->tv_u == 8) TV_ACCEL(8, 0); else TV_ACCEL(4, 0); }
+  if (c->tv_nt) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 4) TV_ACCEL(4, 1); else TV_ACCEL(8, 1); }
+  else { if (c->tv_u == 2) TV_ACCEL(2, 0); else if (c->tv_u == 4) TV_ACCEL(4, 0); else TV_ACCEL(8, 0); }
 #undef TV_ACCEL
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// z-free one-pass stencil step (k_tv_onepass): accel = 0 -> x0 = X[xi]; accel = 1 -> the lazily-kept (P1, P0, c) state
+static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int restart) {
+  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
+    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
+  TvZP p;
+  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
+  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 128);         // rows+4 rows are read per chunk: 128 keeps that at 3 %
+  const int tvu = c->tv_u ? c->tv_u : (accel ? 4 : 2);
+  p.strip_groups = ((p.W + TVZ_OWN - 1) / TVZ_OWN + 3) / 4;
+  if (accel) { p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn); p.cprev = c->lc; }
+  else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }
+  p.b = c->b; p.tau = tau; p.coef = coef; p.restart = restart;
+  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
+  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
+  t_begin(c, FH_K_FUSED);
+#define TVZ(ID, AC, U, NT) k_tv_onepass<ID, AC, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
+#define TVZ_U(ID, AC, NT) do { if (tvu == 2) TVZ(ID, AC, 2, NT); else if (tvu == 8) TVZ(ID, AC, 8, NT); else TVZ(ID, AC, 4, NT); } while (0)
+#define TVZ_NT(ID, AC) do { if (c->tv_nt) TVZ_U(ID, AC, 1); else TVZ_U(ID, AC, 0); } while (0)
+  const bool ident = c->prox_kind != FH_PROX_TVBALL;
+  if (accel) { if (ident) TVZ_NT(1, 1); else TVZ_NT(0, 1); }
+  else { if (ident) TVZ_NT(1, 0); else TVZ_NT(0, 0); }
+#undef TVZ_NT
+#undef TVZ_U
+#undef TVZ
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
+  c->tvz_pending = true;
   return 0;
 }
 
@@ -1346,7 +1405,14 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(not_lazy(c, "fh_step"));
   if (c->op == OP_STENCIL) {
     if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
-    FH_TRY(launch_fused_tv(c, tau));
+    if (c->tv_zfree) {
+      if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
+      FH_TRY(launch_tv_onepass(c, tau, 0, 0.0, 0));
+    } else {
+      FH_TRY(tv_refresh_zcur(c));
+      c->tvz_pending = false;
+      FH_TRY(launch_fused_tv(c, tau));
+    }
     c->last_accel = false;
     return fetch_scalars(c, scalars);
   }
@@ -1394,7 +1460,8 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
       c->lc = c->lbc = c->lc_pending = 0.0;
       lazy_pick_targets(c);
     }
-    FH_TRY(launch_fused_tv_accel(c, tau, coef, restart ? 1 : 0));
+    if (c->tv_zfree) FH_TRY(launch_tv_onepass(c, tau, 1, coef, restart ? 1 : 0));
+    else FH_TRY(launch_fused_tv_accel(c, tau, coef, restart ? 1 : 0));
     c->last_accel = true;
     FH_TRY(fetch_scalars(c, scalars));
     c->lc_pending = (restart && c->hscal[FH_S_RDOT] > 1E-30) ? 0.0 : coef;      // what the launch applied (:231); adopted by fh_commit
@@ -1433,6 +1500,8 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
 extern "C" int fh_commit(fh_ctx* c, int save_best) {
   FH_TRY(check_ready(c, false));
   c->commits += 1;
+  if (c->op == OP_STENCIL && c->tvz_pending && !c->lazy) c->zcur_stale = true;     // the adopted x0 has no stored image
+  c->tvz_pending = false;
   if (c->lazy) {                                    // rotate the (P1, P0, c) / (Z1, Z0, c) state; nothing is copied
     c->lq0 = c->lq1; c->lq1 = c->lqn;
     c->lz0 = c->lz1; c->lz1 = c->lzn;

@@ -117,9 +117,27 @@ __device__ __forceinline__ double bb_dgrad(double g1, double xhat, double x0, do
   return g1 + q;
 }
 
+// The same with the quotient by a launch-uniform tau formed from its reciprocal (rtau = 1/tau, correctly rounded, computed once
+// per thread): q = d*rtau, one exact-remainder correction (Markstein).  The result is the correctly rounded quotient except in
+// rare corner cases (tau's significand all ones, subnormal quotients), where it is off by one ulp -- used ONLY where Dg feeds the
+// Barzilai-Borwein SUMS (<Dx,Dg>, ||Dg||^2), whose summation order already differs from NumPy's by far more than that; it
+// replaces two ~25-instruction IEEE divisions per pixel in the stencil sweeps, which are otherwise ALU-co-limited.
+__device__ __forceinline__ double bb_dgrad_rcp(double g1, double xhat, double x0, double tau, double rtau) {
+#pragma clang fp contract(off)
+  const double d = xhat - x0;
+  double q = d * rtau;
+  const double e = __builtin_fma(-q, tau, d);
+  q = __builtin_fma(e, rtau, q);
+  return g1 + q;
+}
+
 __device__ __forceinline__ double sub_nofma(double a, double b) {
 #pragma clang fp contract(off)
   return a - b;
+}
+__device__ __forceinline__ double add_nofma(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
 }
 
 // scalar slots (mirror include/fasta_hip.h enum fh_scalar)

@@ -854,3 +854,236 @@ __global__ __launch_bounds__(FH_WG) void k_extrapolate_vec(double* out, const do
   for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < len; i += (uint64_t)gridDim.x * FH_WG)
     out[i] = coef != 0.0 ? extrapolate(a[i], b[i], coef) : a[i];
 }
+
+// =================================================================================================
+// ONE-PASS stencil iteration that does not touch z at all (round 2; replaces k_fused_tv_step / k_fused_tv_accel as the
+// default `fh_step` / `fh_step_accel` path of the stencil operator).
+//
+// z = div(x) is a 3-point combination of values the sweep is reading anyway, so the residual source z_cur = div(x0) is
+// RECOMPUTED from the x0 rows in flight instead of being read (8 B/pixel), and z_new = div(xprox) -- needed only for this
+// iteration's f, g1 and BB sums -- is never WRITTEN (8 B/pixel): the next sweep recomputes it from the xprox it reads.
+// Every recomputed value is the same IEEE expression on the same inputs as the reference's z1 = A(x1) (fasta/__init__.py:187),
+// so the bits do not change.  With FISTA (ACCEL) the image of the extrapolated point is z1 + c (z1 - z_accel0) with
+// z1 = div(P1), z_accel0 = div(P0) (:243): both are recomputed, separately, from the two prox outputs the sweep reads.
+//   per pixel: reads x0 16 + b 8, writes xprox 16 = 40 B   (k_fused_tv_step: 56 B; two launches: 112 B; model: 136 B)
+//   FISTA    : reads P1 16 + P0 16 + b 8, writes 16   = 56 B   (k_fused_tv_accel: 80 B; two launches: 160 B)
+// Software pipeline over the rows s = i0-2 .. i0+rows+1 of a chunk (row s "arrives" = its loads are consumed):
+//   A  z_cur, r_cur of row s-1      from x rows s-1, s and the right neighbour          (lanes 0..62 valid)
+//   B  g0, xhat, xprox of row s-1   from r_cur rows s-2, s-1 and the left neighbour      (lanes 1..62)   -> store xprox, forward sums
+//   C  z_new, r_new of row s-2      from xprox rows s-2, s-1 and the right neighbour     (lanes 1..61)
+//   D  g1 and the BB sums of row s-2 from r_new rows s-3, s-2 and the left neighbour     (lanes 2..61 = the 60 owned columns)
+// so a wave strip owns 60 columns (two halo lanes per side) and a chunk reads rows+4 rows for `rows` owned ones.
+// =================================================================================================
+#define TVZ_OWN 60
+
+// neighbour exchange by DPP wavefront shifts (VALU, no LDS crossbar round trip): lane i <- lane i-1 / lane i+1; the end lane
+// keeps its own value (it is a halo lane whose result is never used)
+__device__ __forceinline__ double tvz_from_left(double v) {       // == __shfl_up(v, 1)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xF, 0xF, false);   // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tvz_from_right(double v) {      // == __shfl_down(v, 1)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);   // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+struct TvZP {
+  uint32_t H, W, strip_groups, rows_wg;
+  const double* p1; const double* p0;   // (H,W,2): x0 = p1 (ACCEL: p1 + cprev*(p1 - p0), the last two prox outputs)
+  double* pn;                            // (H,W,2): this step's prox output
+  const double* b;                       // (H,W)
+  double tau, cprev, coef;
+  int restart;
+  double* red; unsigned* counter; double* out;
+};
+
+template <int IDENT, int ACCEL, int TV_U, int NT>
+__global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
+  __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t i0 = rc * p.rows_wg;
+  const uint32_t rows = min(p.rows_wg, p.H - i0);
+  const uint32_t first = (sg * 4u + wave) * TVZ_OWN;
+  const uint32_t cw = (first + lane + 2u * p.W - 2u) % p.W;       // lane L <-> image column first + L - 2 (periodic)
+  const uint32_t c = first + lane - 2u;                           // valid as an index only for owning lanes
+  const bool own = lane >= 2u && lane <= 61u && c < p.W;
+  const bool lag = ACCEL && p.cprev != 0.0;                       // uniform: the previous step extrapolated
+  const double rtau = 1.0 / p.tau;
+  double v[5] = {0, 0, 0, 0, 0};                                  // dxg0, dx2, xh2, g02, restart dot
+  double u0[4] = {0, 0, 0, 0};                                    // c = 0     : dxdg, dg2, gsum, gmax   (xh2 = v[2], f = fs)
+  double u1[6] = {0, 0, 0, 0, 0, 0};                              // c = coef  : dxdg, dg2, xh2, gsum, gmax, f   (ACCEL only)
+  double fs = 0.0;
+
+  auto row_of = [&](int off) -> uint32_t {                        // (i0 + off) mod H, periodic
+    const int64_t Hh = (int64_t)p.H;
+    return (uint32_t)((((int64_t)i0 + off) % Hh + Hh) % Hh);
+  };
+  auto div_at = [&](d2 me, d2 below) -> double {                  // div of one field at (row, col) given the row below; right neighbour by shuffle
+    const double right_y = tvz_from_right(me.y);
+    const double a0 = sub_nofma(below.x, me.x);                   // roll(Y0, -1, axis 0) - Y0
+    const double a1 = sub_nofma(right_y, me.y);                   // roll(Y1, -1, axis 1) - Y1
+    return add_nofma(a0, a1);
+  };
+
+  // rolling state: index 1 = row s-1, index 2 = row s-2
+  d2 P1a = {0, 0}, P0a = {0, 0};               // prox outputs of row s-1 (loaded)
+  double b1 = 0.0, b2 = 0.0;                   // targets of rows s-1, s-2
+  double rc2 = 0.0;                            // r_cur of row s-2
+  d2 x0_2 = {0, 0}, xh_2 = {0, 0}, xp_2 = {0, 0}, q1_2 = {0, 0};   // row s-2: x0, xhat, xprox, P1 (x_accel0 of this step)
+  double z1_2 = 0.0;                           // row s-2: div(P1) (z_accel0 of this step)
+  double rn0_3 = 0.0, rn1_3 = 0.0;             // r_new of row s-3 (both candidates)
+
+  const int total = (int)rows + 4;             // rows i0-2 .. i0+rows+1
+  for (int t0 = 0; t0 < total; t0 += TV_U) {
+    d2 xv1[TV_U], xv0[TV_U];
+    double bv[TV_U];
+    uint64_t npix[TV_U];
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const int s = min(t0 + q, total - 1) - 2;                   // clamp past the chunk (loads stay in bounds, rows not consumed)
+      npix[q] = (uint64_t)row_of(s) * p.W + cw;
+      xv1[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p1) + npix[q]);
+      bv[q] = load_f64<NT>(p.b + npix[q]);
+      xv0[q] = (d2){0.0, 0.0};
+      if (lag) xv0[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p0) + npix[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < TV_U; ++q) {
+      const int s = t0 + q - 2;                                    // relative row that arrives now
+      if (t0 + q < total) {                                        // wave-uniform
+        if (s >= -1) {
+          // ---- A: image of x0 at row s-1 and its residual ----
+          const double z1v = div_at(P1a, xv1[q]);                  // div(P1) at row s-1
+          double zc = z1v;
+          if (lag) zc = extrapolate(z1v, div_at(P0a, xv0[q]), p.cprev);       // (:243 of the previous iteration)
+          const double rc1 = sub_nofma(zc, b1);
+          if (s >= 0) {
+            // ---- B: forward point and prox at row s-1 ----
+            const double r_left = tvz_from_left(rc1);
+            d2 x0v = P1a;
+            if (lag) { x0v.x = extrapolate(P1a.x, P0a.x, p.cprev); x0v.y = extrapolate(P1a.y, P0a.y, p.cprev); }   // (:242)
+            d2 g0v, xh;
+            g0v.x = sub_nofma(rc2, rc1);
+            g0v.y = sub_nofma(r_left, rc1);
+            xh.x = fwd_point(x0v.x, g0v.x, p.tau);
+            xh.y = fwd_point(x0v.y, g0v.y, p.tau);
+            const d2 xp = IDENT ? xh : tv_ball(xh);
+            if (own && s >= 1 && s <= (int)rows) {                 // row s-1 in [0, rows)
+              store_d2<NT>(reinterpret_cast<d2*>(p.pn) + (uint64_t)(i0 + s - 1) * p.W + c, xp);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const double dx = sub_nofma(xp[e], x0v[e]);
+                const double dh = sub_nofma(xp[e], xh[e]);
+                v[0] = fma(dx, g0v[e], v[0]);
+                v[1] = fma(dx, dx, v[1]);
+                v[2] = fma(dh, dh, v[2]);
+                v[3] = fma(g0v[e], g0v[e], v[3]);
+                if (ACCEL) v[4] = fma(sub_nofma(x0v[e], xp[e]), sub_nofma(xp[e], P1a[e]), v[4]);      // x_accel0 = P1 (:222, :231)
+              }
+            }
+            if (s >= 1) {
+              // ---- C: z_new and r_new of row s-2 ----
+              const double zo = div_at(xp_2, xp);
+              const double rn0 = sub_nofma(zo, b2);
+              double rn1 = rn0;
+              if (ACCEL) rn1 = sub_nofma(extrapolate(zo, z1_2, p.coef), b2);                           // z_accel0 = div(P1) (:224, :243)
+              const double rn0_left = tvz_from_left(rn0);
+              double rn1_left = rn0_left;
+              if (ACCEL) rn1_left = tvz_from_left(rn1);
+              if (own && s >= 2) {                                 // ---- D: row s-2 in [0, rows) ----
+                fs = fma(rn0, rn0, fs);
+                if (ACCEL) u1[5] = fma(rn1, rn1, u1[5]);
+                d2 ga, gb;
+                ga.x = sub_nofma(rn0_3, rn0);  ga.y = sub_nofma(rn0_left, rn0);
+                gb.x = sub_nofma(rn1_3, rn1);  gb.y = sub_nofma(rn1_left, rn1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const double dx = sub_nofma(xp_2[e], x0_2[e]);
+                  const double dga = bb_dgrad_rcp(ga[e], xh_2[e], x0_2[e], p.tau, rtau);
+                  u0[0] = fma(dx, dga, u0[0]);
+                  u0[1] = fma(dga, dga, u0[1]);
+                  u0[2] += fabs(xp_2[e]);
+                  u0[3] = fmax(u0[3], fabs(xp_2[e]));
+                  if (ACCEL) {
+                    const double dgb = bb_dgrad_rcp(gb[e], xh_2[e], x0_2[e], p.tau, rtau);
+                    const double x1 = extrapolate(xp_2[e], q1_2[e], p.coef);                          // (:242)
+                    const double dh = sub_nofma(x1, xh_2[e]);
+                    u1[0] = fma(dx, dgb, u1[0]);
+                    u1[1] = fma(dgb, dgb, u1[1]);
+                    u1[2] = fma(dh, dh, u1[2]);
+                    u1[3] += fabs(x1);
+                    u1[4] = fmax(u1[4], fabs(x1));
+                  }
+                }
+              }
+              rn0_3 = rn0; rn1_3 = rn1;
+            }
+            x0_2 = x0v; xh_2 = xh; xp_2 = xp; q1_2 = P1a; z1_2 = z1v;
+          }
+          rc2 = rc1;
+        }
+        b2 = b1;
+        P1a = xv1[q]; P0a = xv0[q]; b1 = bv[q];
+      }
+    }
+  }
+  // partials per workgroup: [0] fs [1..4] v0..v3 [5] rdot [6..8] u0 dxdg, dg2, gsum [9..13] u1 dxdg, dg2, xh2, gsum, f  [14] u0 gmax [15] u1 gmax
+  {
+    double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], u0[0], u0[1]};
+    block_reduce<8>(w, s_scr, -1);
+    double w2[6] = {u0[2], u1[0], u1[1], u1[2], u1[3], u1[5]};
+    block_reduce<6>(w2, s_scr, -1);
+    { const double m0 = wave_max(u0[3]), m1 = wave_max(u1[4]); if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; } }
+    __syncthreads();
+    if (tid == 0) {
+      double* slot = p.red + (uint64_t)blockIdx.x * 16;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) store_partial(slot + k, w[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) store_partial(slot + 8 + k, w2[k]);
+      store_partial(slot + 14, fmax(fmax(s_scr[0], s_scr[2]), fmax(s_scr[4], s_scr[6])));
+      store_partial(slot + 15, fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7])));
+    }
+  }
+  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  double t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = 0.0;
+  for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double qv = load_partial(p.red + (uint64_t)i * 16 + k);
+      if (k >= 14) t[k] = fmax(t[k], qv); else t[k] += qv;
+    }
+  }
+  {
+    double a[8] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]};
+    block_reduce<8>(a, s_scr, -1);
+    double bq[6] = {t[8], t[9], t[10], t[11], t[12], t[13]};
+    block_reduce<6>(bq, s_scr, -1);
+    const double m0 = wave_max(t[14]), m1 = wave_max(t[15]);
+    if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; }
+    __syncthreads();
+    if (tid == 0) {
+      const double gmax0 = fmax(fmax(s_scr[0], s_scr[2]), fmax(s_scr[4], s_scr[6]));
+      const double gmax1 = fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7]));
+      const double rdot = ACCEL ? a[5] : 0.0;
+      const bool plain = !ACCEL || (p.restart && rdot > 1E-30) || p.coef == 0.0;      // :231 -- the branch the reference takes
+      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
+      p.out[S_GSUM] = bq[0]; p.out[S_GMAX] = gmax0; p.out[S_RDOT] = rdot;
+      p.out[S_DXDG] = plain ? a[6] : bq[1];
+      p.out[S_DG2] = plain ? a[7] : bq[2];
+      p.out[S_XH2_ADJ] = plain ? a[3] : bq[3];
+      p.out[S_GSUM_ADJ] = plain ? bq[0] : bq[4];
+      p.out[S_GMAX_ADJ] = plain ? gmax0 : gmax1;
+      p.out[S_FSQ_ADJ] = plain ? a[0] : bq[5];
+      p.out[S_ALPHA] = 0.0;
+      p.out[15] = 0.0;
+      __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}

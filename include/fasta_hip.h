@@ -85,10 +85,12 @@ enum fh_tuning_key {
   FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */
   FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
   FH_TUNE_NT_LOADS = 5,      /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
-  FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads in flight per lane (2, 4, 8)           */
+  FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads in flight per lane (2, 4, 8; 0 = auto)  */
   FH_TUNE_TV_ROWS = 7,       /* stencil kernels: image rows per workgroup (0 = auto)                 */
   FH_TUNE_TV_NT = 8,         /* stencil kernels: non-temporal loads/stores (default 0)               */
-  FH_TUNE_FUSED_VARIANT = 9  /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h)   */
+  FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h)   */
+  FH_TUNE_TV_ZFREE = 10      /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
+                                pixel); 0 = the round-1 kernels that stream z (56 / 80 B per pixel)                          */
 };
 
 /* ---- library / context -------------------------------------------------------------- */

@@ -183,9 +183,11 @@ def test_tv_full_size_adjointness_8192():
         op.close()
 
 
-@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130)])
-def test_one_pass_tv_step_equals_two_launch_step(H_, W_):
-    """fh_step on the stencil operator (k_fused_tv_step) against fh_fwd + fh_adj on the same state."""
+@pytest.mark.parametrize("zfree", [1, 0])
+@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (3, 59), (4, 60), (130, 121), (70, 500)])
+def test_one_pass_tv_step_equals_two_launch_step(H_, W_, zfree):
+    """fh_step on the stencil operator against fh_fwd + fh_adj on the same state: zfree = 1 the default kernel that
+    recomputes z in flight (k_tv_onepass), zfree = 0 the round-1 kernel that streams it (k_fused_tv_step)."""
     rng = np.random.RandomState(H_ * 7 + W_)
     M = rng.randn(H_, W_)
     Y0 = rng.randn(H_, W_, 2) * 0.8
@@ -193,6 +195,7 @@ def test_one_pass_tv_step_equals_two_launch_step(H_, W_):
     op = fa.GradDivMap((H_, W_))
     try:
         c = op.ctx
+        c.set_tuning(hip.TUNE_TV_ZFREE, zfree)
         assert c.fused_supported() == 2
 
         def fresh():
@@ -239,10 +242,11 @@ def test_tv_solve_identical_with_and_without_the_one_pass_kernel():
     np.testing.assert_allclose(a.solution, b.solution, rtol=1e-6, atol=1e-10)
 
 
+@pytest.mark.parametrize("zfree", [1, 0])
 @pytest.mark.parametrize("prox", ["tvball", "identity"])
 @pytest.mark.parametrize("restart", [True, False])
-@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (64, 1000)])
-def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox):
+@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (64, 1000), (130, 121)])
+def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox, zfree):
     """fh_step_accel on the stencil operator (k_fused_tv_accel: both coefficient candidates in one sweep, iterate kept in
     extrapolated-on-the-fly form) in LOCKSTEP with fh_fwd + fh_adj(accel) on a second context: same alpha recursion, same
     backtracking-style retry (a launch repeated with a smaller tau before the commit), several restarts along the way.
@@ -252,6 +256,7 @@ def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, p
     Y0 = rng.randn(H_, W_, 2) * 0.8
     one, two = fa.GradDivMap((H_, W_)), fa.GradDivMap((H_, W_))
     try:
+        one.ctx.set_tuning(hip.TUNE_TV_ZFREE, zfree)
         for c in (one.ctx, two.ctx):
             c.set_loss_lsq(M)
             c.set_prox(hip.PROX_TVBALL if prox == "tvball" else hip.PROX_IDENTITY)
@@ -333,3 +338,38 @@ def test_accelerated_tv_solve_identical_with_and_without_the_one_pass_kernel(res
     G.compare_histories(a, lambda f: getattr(want, f), k, rtol=1e-6, atol=1e-13)
     np.testing.assert_allclose(a.iterates[:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(a.solution, want.solution, rtol=1e-5, atol=1e-9)
+
+
+def test_z_free_steps_can_be_followed_by_two_launch_steps():
+    """The default one-pass stencil step never stores z; when a caller of the C ABI then switches to fh_fwd / fh_adj, the
+    stored image of x0 is brought up to date first (one plain div pass) -- same results as two-launch steps throughout."""
+    rng = np.random.RandomState(5)
+    H_, W_ = 70, 150
+    M = rng.randn(H_, W_)
+    Y0 = rng.randn(H_, W_, 2) * 0.8
+    a, b = fa.GradDivMap((H_, W_)), fa.GradDivMap((H_, W_))
+    try:
+        for c in (a.ctx, b.ctx):
+            c.set_loss_lsq(M)
+            c.set_prox(hip.PROX_TVBALL)
+            c.set_vector(hip.VEC_X0, Y0)
+            c.init()
+        for it, tau in enumerate((0.2, 0.15, 0.22, 0.1, 0.2, 0.18)):
+            zfree_step = it in (0, 1, 3)
+            if zfree_step:
+                sa = a.ctx.step(tau)
+            else:
+                sa = a.ctx.fwd(tau)
+                sa2 = a.ctx.adj(tau)
+            sb = b.ctx.fwd(tau)
+            sb2 = b.ctx.adj(tau)
+            np.testing.assert_allclose(sa[hip.S_FSQ], sb[hip.S_FSQ], rtol=1e-12)
+            np.testing.assert_allclose((sa if zfree_step else sa2)[hip.S_DXDG], sb2[hip.S_DXDG], rtol=1e-10, atol=1e-300)
+            assert np.array_equal(a.ctx.get_vector(hip.VEC_XPROX, Y0.size), b.ctx.get_vector(hip.VEC_XPROX, Y0.size)), it
+            assert np.array_equal(a.ctx.get_vector(hip.VEC_Z, M.size), b.ctx.get_vector(hip.VEC_Z, M.size)), it
+            a.ctx.commit(save_best=(it == 2))
+            b.ctx.commit(save_best=(it == 2))
+        assert np.array_equal(a.ctx.get_vector(hip.VEC_BEST, Y0.size), b.ctx.get_vector(hip.VEC_BEST, Y0.size))
+    finally:
+        a.close()
+        b.close()
