@@ -2,7 +2,7 @@
 # it/s and per-kernel rates of the dense LASSO bench across matrix sizes (GPU box).  Usage: bash scripts/sizes.sh
 for s in "512 1024" "2048 2048" "4096 4096" "8192 8192" "16384 16384" "32768 32768" "65536 65536"; do
   set -- $s
-  python bench.py --rows $1 --cols $2 --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | python -c "
+  python bench.py --rows $1 --cols $2 --steps 40 --warmup 5 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 pk=d['roofline']['per_kernel']

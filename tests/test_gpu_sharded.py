@@ -23,9 +23,12 @@ def _prepare(op, b, x0, g0, mu=0.02):
     return c
 
 
-@pytest.mark.parametrize("m,n,one_pass", [(300, 4096, True), (300, 4096, False), (2 * 32768, 65536, True), (2 * 32768, 65536, False)])
-def test_two_row_blocks_sum_to_the_unsharded_launch(m, n, one_pass):
-    """(m/2 x n) per emulated rank; 32768 x 65536 is BASELINE config 5's per-GPU shard shape."""
+@pytest.mark.parametrize("m,n,one_pass,storage", [(300, 4096, True, "f64"), (300, 4096, False, "f64"), (2 * 32768, 65536, True, "f64"),
+                                                  (2 * 32768, 65536, False, "f64"), (300, 20000, True, "f32"), (2 * 8192, 65536, True, "f32"),
+                                                  (200, 100000, True, "f64")])
+def test_two_row_blocks_sum_to_the_unsharded_launch(m, n, one_pass, storage):
+    """(m/2 x n) per emulated rank; 32768 x 65536 is BASELINE config 5's per-GPU shard shape.  Also in float32 storage and on
+    a wide-row shape (x slice in LDS)."""
     scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
     rng = np.random.RandomState(4)
     x0 = rng.randn(n) * 0.1
@@ -33,8 +36,8 @@ def test_two_row_blocks_sum_to_the_unsharded_launch(m, n, one_pass):
     b = rng.randn(m)
     tau = 0.7
     half = m // 2
-    whole = fa.DenseMatrixMap.synthetic(m, n, 0, scale)
-    shards = [fa.DenseMatrixMap.synthetic(half, n, 0, scale, row0=k * half, m_total=m) for k in range(2)]
+    whole = fa.DenseMatrixMap.synthetic(m, n, 0, scale, storage=storage)
+    shards = [fa.DenseMatrixMap.synthetic(half, n, 0, scale, row0=k * half, m_total=m, storage=storage) for k in range(2)]
     try:
         # the shards really are the two row blocks of the same matrix
         for k, r in ((0, 0), (0, half - 1), (1, 0), (1, half - 1)):
