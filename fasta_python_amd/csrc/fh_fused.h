@@ -73,8 +73,10 @@ __device__ __forceinline__ double ft_wave_sum(double v) {       // every lane ge
 // -DFT_PROFILE: wave 0 of block 0 accumulates s_memtime ticks per phase of the row loop and prints them (debug builds only)
 #ifdef FT_PROFILE
 #define FT_T(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); prof[i] += _t - tprev; tprev = _t; } while (0)
+#define FT_PHASE(i) do { phase[i] = __builtin_amdgcn_s_memrealtime(); } while (0)     /* 100 MHz wall clock of the whole launch's phases */
 #else
 #define FT_T(i) do { } while (0)
+#define FT_PHASE(i) do { } while (0)
 #endif
 
 struct FusedP {
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   typedef typename PieceOf<F32>::type PT;
   constexpr int XD = xd2<F32>();                  // double pairs of x / g1 per 16-byte piece of A
   __shared__ __attribute__((aligned(16))) d2 s_x[XLDS ? PPT * XD * FH_WG : 1];
+  __shared__ __attribute__((aligned(16))) d2 s_fin[FH_WG];       // finalise: per-slice partial sums of the team partials
   __shared__ __attribute__((aligned(16))) double s_part[4];
   __shared__ __attribute__((aligned(16))) double s_part2[2][4];  // TEAM == 1: wave partials, double-buffered by trip parity
   __shared__ __attribute__((aligned(16))) double s_bc[2];       // broadcast: r_i
@@ -133,6 +136,10 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   // group and keeps it a template parameter)
   const int kind = p.px.kind;
   const double level = (kind == PX_LINF || kind == PX_L1BALL) ? *p.px.level : 0.0;
+#ifdef FT_PROFILE
+  unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  FT_PHASE(0);
 
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
   d2 xq[XLDS ? 1 : PPT][XD];
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   }
 
+  FT_PHASE(1);
   // ---------------- rows of this team: one pass, three rotating register buffers ----------------------------
   // Row numbers below are TEAM-LOCAL (0 .. r_end-1); grow() maps them to rows of A.  Default: blocked (team t owns a
   // contiguous range of rows_per_team rows); variant bit 32: row-cyclic over the teams (t, t+nteams, ...), i.e. the whole
@@ -472,6 +480,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
            (double)prof[3] / (r_end - r_begin), (double)prof[4] / (r_end - r_begin), (double)prof[5] / (r_end - r_begin),
            (double)prof[6] / (r_end - r_begin), (double)prof[7] / (r_end - r_begin));
 #endif
+  FT_PHASE(2);
   // ---------------- loss terms of this team's rows (member 0), off the exchange's critical path: keeping log/exp of the
   // logistic objective out of the row loop also keeps their constants out of its (full) register budget
   if (mem == 0) {
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     }
   }
 
+  FT_PHASE(3);
   // ---------------- bounded grid barrier (all workgroups are co-resident: one per CU) -----------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -520,18 +530,38 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   }
   __syncthreads();
 
+  FT_PHASE(4);
   // ---------------- every workgroup finalises its share of the columns: team-ordered sum + n-side epilogue ----
   AdjP e;                                            // reuse K-adj's per-element epilogue
   e.accel = p.accel; e.coef = coef; e.tau = p.tau;
   double u[5] = {0, 0, 0, 0, 0};                     // dxdg, dg2, xh2, gsum, gmax
   const uint32_t share = (p.nv2 + gridDim.x - 1) / gridDim.x;
-  for (uint32_t t = tid; t < share; t += FH_WG) {
-    const uint32_t c = blockIdx.x * share + t;       // double-pair index into the n-side vectors
-    if (c >= p.nv2) continue;
-    const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
+  // A workgroup's share is often far fewer columns than it has threads (n = 8192: 16 double pairs) while every column sums
+  // nteams partials (up to 256) through L2: the threads split the TEAMS of a column between them (`slices` contiguous team
+  // ranges per column, summed in team order, then added in slice order -- a fixed order, so still bitwise repeatable).
+  const uint32_t slices = share < FH_WG ? min(FH_WG / max(share, 1u), p.nteams) : 1u;
+  const uint32_t tps = (p.nteams + slices - 1) / slices;              // teams per slice
+  for (uint32_t t0 = 0; t0 < share; t0 += FH_WG) {
+    const uint32_t col = slices > 1 ? tid % share : t0 + tid;
+    const uint32_t slice = slices > 1 ? tid / share : 0u;
+    const uint32_t c = blockIdx.x * share + col;     // double-pair index into the n-side vectors
+    const bool mine = col < share && slice < slices && c < p.nv2;
     d2 g = {0.0, 0.0};
+    if (mine) {
+      const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
+      const uint32_t s1 = min((slice + 1u) * tps, p.nteams);
 #pragma unroll 8
-    for (uint32_t s = 0; s < p.nteams; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
+      for (uint32_t s = slice * tps; s < s1; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
+    }
+    if (slices > 1) {                                // uniform over the workgroup
+      __syncthreads();
+      if (mine) s_fin[slice * share + col] = g;
+      __syncthreads();
+      if (mine && slice == 0) {
+        for (uint32_t q = 1; q < slices; ++q) g += s_fin[q * share + col];
+      }
+    }
+    if (!mine || slice != 0) continue;
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
       // xhat / xp were written by team 0 with plain stores earlier in THIS launch: read them back through sc1
@@ -551,6 +581,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) store_partial(p.red + (uint64_t)blockIdx.x * 16 + 8 + k, u[k]);
   }
+  FT_PHASE(5);
+#ifdef FT_PROFILE
+  if (blockIdx.x == 0 && tid == 0)
+    printf("fused phases (block 0, us): prologue %.1f | rows %.1f | loss+publish %.1f | grid barrier %.1f | finalise %.1f\n",
+           (phase[1] - phase[0]) * 0.01, (phase[2] - phase[1]) * 0.01, (phase[3] - phase[2]) * 0.01, (phase[4] - phase[3]) * 0.01, (phase[5] - phase[4]) * 0.01);
+#endif
   if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
   double w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
