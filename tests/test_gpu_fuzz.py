@@ -95,3 +95,65 @@ def test_custom_stop_rule_and_matrix_valued_iterate_shapes():
         op.close()
     assert c.iteration_count == 3 and [a[0] for a in calls] == [0, 1, 2] and calls[0][4] == 0.5
     assert c.solution.shape == (12, 10, 2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_stencil_shapes_and_modes(seed):
+    """TV dual on random image shapes (1 x 1 up to a few strips wide), every mode, non-zero starts, record_iterates
+    (which materialises the lazily-kept FISTA iterate every iteration): the default one-pass sweeps against the oracle's
+    roll-based loop, 25 iterations (before the adaptive runs turn chaotic)."""
+    rng = np.random.RandomState(2000 + seed)
+    H_, W_ = int(rng.randint(1, 140)), int(rng.randint(1, 260))
+    M = rng.randn(H_, W_)
+    mu = 0.2 + rng.rand()
+    Y0 = rng.randn(H_, W_, 2) * (0.4 if seed % 2 else 0.0)
+    adaptive, accelerate = [(True, False), (False, True), (False, False), (True, True)][seed % 4]
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=25, tolerance=0.0, evaluate_objective=bool(seed % 3),
+                record_iterates=bool(seed % 2), restart=bool((seed // 2) % 2), window=int(rng.randint(1, 12)))
+    P = pr.tv_denoising_from(M, mu)
+    op = fa.GradDivMap((H_, W_))
+    try:
+        ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        solver = fa.FBSolver(op, ls, reg, Y0, verbose=False, **opts)
+        np.random.seed(seed)
+        got = solver.setup().run()
+        assert solver.fused_steps == got.iteration_count + got.backtracks        # every launch was a one-pass sweep
+    finally:
+        op.close()
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, Y0, **opts)
+    _same(got, want)
+    if opts["record_iterates"]:
+        np.testing.assert_allclose(got.iterates, want.iterates, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_and_modes_in_float32_storage(seed):
+    """Dense operator stored in float32 on random ragged shapes, every mode: the solve is the oracle's solve on the rounded
+    matrix, to the float64 path's tolerances."""
+    rng = np.random.RandomState(3000 + seed)
+    m, n = int(rng.randint(1, 180)), int(rng.randint(1, 3000))
+    A = (rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))).astype(np.float32).astype(np.float64)      # exactly representable
+    b = rng.randn(m)
+    x0 = rng.randn(n) * (0.1 if seed % 2 else 0.0)
+    kind = ("shrink", "nonneg", "l1ball")[seed % 3]
+    adaptive, accelerate = [(True, False), (False, True), (False, False), (True, True)][seed % 4]
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=60, tolerance=1e-7, evaluate_objective=bool(seed % 2),
+                restart=bool((seed // 2) % 2))
+    reg = {"shrink": fa.Shrink(0.05), "nonneg": fa.NonNeg(), "l1ball": fa.L1Ball(0.05)}[kind]
+    P = {"shrink": lambda: pr.sparse_least_squares_from(A, b, 0.05), "nonneg": lambda: pr.nn_least_squares_from(A, b),
+         "l1ball": lambda: pr.l1_ball_lasso_from(A, b, 0.05)}[kind]()
+    op = fa.DenseMatrixMap(A, storage="f32")
+    try:
+        ls = fa.LeastSquares(b)
+        np.random.seed(seed)
+        got = fa.fasta(op, op.H, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", fused=bool(seed % 2) or "auto", **opts)
+    finally:
+        op.close()
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **opts)
+    _same(got, want)
