@@ -459,8 +459,8 @@ def main(argv=None):
                      "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "stream_read_ceiling_GB/s": ceil_bytes / ceil_ms / 1e6,
-                     "stream_read_probe": "k_stream_probe<8,1>: K-fwd's launch shape (8-row groups, <=2 persistent workgroups/CU, "
-                                          "16 non-temporal 16-byte loads in flight per lane), loads + adds only",
+                     "stream_read_probe": "k_stream_probe<16,1> over the same device copy of A: one persistent workgroup per CU, three rotating "
+                                          "register buffers of 16 non-temporal 16-byte loads per lane (32 loads in flight), loads + adds only",
                      "per_kernel": main_r["per_kernel"],
                      "loop_GB/s_wallclock": main_r["loop_GB/s_wallclock"],
                      "vs_two_pass_model": main_r["vs_two_pass_model"],
