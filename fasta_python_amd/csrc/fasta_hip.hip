@@ -437,6 +437,17 @@ extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n,
   return finish(c);
 }
 
+// float32 host matrix straight into a float32-storage context (no float64 detour on either side)
+extern "C" int fh_set_matrix_f32(fh_ctx* c, const float* A, uint64_t m, uint64_t n, uint64_t ld_host) {
+  if (!c || !A) return fail(FH_E_ARG, "fh_set_matrix_f32: null argument");
+  if (!c->f32) return fail(FH_E_STATE, "fh_set_matrix_f32 needs a float32-storage context (fh_create_ex with FH_DTYPE_F32_STORAGE)");
+  if (ld_host < n) return fail(FH_E_ARG, "fh_set_matrix_f32: ld_host %llu < n %llu", (unsigned long long)ld_host, (unsigned long long)n);
+  FH_TRY(setup_dense(c, m, n));
+  HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * sizeof(float), c->stream));
+  HIP_TRY(hipMemcpy2DAsync(c->A, c->ld * sizeof(float), A, ld_host * sizeof(float), n * sizeof(float), m, hipMemcpyHostToDevice, c->stream));
+  return finish(c);
+}
+
 extern "C" int fh_generate_matrix(fh_ctx* c, uint64_t m, uint64_t n, uint64_t row0, uint64_t seed, double coef) {
   if (!c) return fail(FH_E_ARG, "null context");
   FH_TRY(setup_dense(c, m, n));

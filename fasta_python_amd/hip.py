@@ -40,6 +40,7 @@ SIGNATURES = {
     "fh_sync": (_i32, [_ctx]),
     "fh_set_tuning": (_i32, [_ctx, _i32, C.c_longlong]),
     "fh_set_matrix": (_i32, [_ctx, _pd, _u64, _u64, _u64]),
+    "fh_set_matrix_f32": (_i32, [_ctx, C.POINTER(C.c_float), _u64, _u64, _u64]),
     "fh_generate_matrix": (_i32, [_ctx, _u64, _u64, _u64, _u64, _dbl]),
     "fh_get_matrix_rows": (_i32, [_ctx, _u64, _u64, _pd]),
     "fh_set_stencil": (_i32, [_ctx, _u64, _u64]),
@@ -166,6 +167,11 @@ class HipContext:
 
     def set_matrix(self, A):
         assert A.ndim == 2
+        if self.storage == "f32" and A.dtype == np.float32:           # float32 data into float32 storage: no float64 detour
+            A = np.ascontiguousarray(A)
+            m, n = A.shape
+            self._call("fh_set_matrix_f32", A.ctypes.data_as(C.POINTER(C.c_float)), m, n, n)
+            return
         if A.dtype != np.float64 or not A.flags.c_contiguous:
             A = np.ascontiguousarray(A, dtype=np.float64)
         m, n = A.shape

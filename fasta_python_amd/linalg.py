@@ -37,10 +37,10 @@ class LinearMap:
         self.Vshape, self.Wshape = tuple(Vshape), tuple(Wshape)
 
     @staticmethod
-    def from_matrix(A, device=0):
-        """fasta/linalg.py:37-41.  Returns a device-resident DenseMatrixMap."""
+    def from_matrix(A, device=0, storage="f64"):
+        """fasta/linalg.py:37-41.  Returns a device-resident DenseMatrixMap (storage="f32": opt-in float32 storage of A)."""
         assert A.ndim == 2
-        return DenseMatrixMap(A, device=device)
+        return DenseMatrixMap(A, device=device, storage=storage)
 
     @staticmethod
     def identity(shape):

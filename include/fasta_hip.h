@@ -111,6 +111,8 @@ int fh_set_tuning(fh_ctx* ctx, int key, long long value);
 /* ---- operator A (replaces LinearMap.from_matrix closures `A @ x`, `A.T @ x`, fasta/linalg.py:37-41) */
 /* dense row-major host matrix, m rows, n columns, leading dimension ld_host (doubles).          */
 int fh_set_matrix(fh_ctx* ctx, const double* A, uint64_t m, uint64_t n, uint64_t ld_host);
+/* float32 host matrix into a float32-storage context (fh_create_ex, FH_DTYPE_F32_STORAGE): copied as is, no rounding step  */
+int fh_set_matrix_f32(fh_ctx* ctx, const float* A, uint64_t m, uint64_t n, uint64_t ld_host);
 /* synthetic rows [row0, row0+m) of a (.., n) matrix: element (i,j) = ihall(seed, (row0+i)*n + j) * coef
  * (device twin of oracle/problems.py:synth_values).                                            */
 int fh_generate_matrix(fh_ctx* ctx, uint64_t m, uint64_t n, uint64_t row0, uint64_t seed, double coef);

@@ -43,6 +43,25 @@ def test_operator_is_the_rounded_matrix(m, n):
         op.close()
 
 
+def test_float32_host_matrix_goes_in_without_a_float64_detour():
+    rng = np.random.RandomState(3)
+    A32 = rng.randn(45, 300).astype(np.float32)
+    x = rng.randn(300)
+    op = fa.LinearMap.from_matrix(A32, storage="f32")
+    try:
+        assert np.array_equal(op.host_rows(0, 45), A32.astype(np.float64))
+        np.testing.assert_allclose(op(x), A32.astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
+    finally:
+        op.close()
+    import ctypes as C
+    op = fa.DenseMatrixMap(np.zeros((2, 2)))                                  # float64 context refuses the float32 entry point
+    try:
+        buf = np.zeros((2, 2), dtype=np.float32)
+        assert op.ctx.lib.fh_set_matrix_f32(op.ctx._h, buf.ctypes.data_as(C.POINTER(C.c_float)), 2, 2, 2) != 0
+    finally:
+        op.close()
+
+
 def test_synthetic_generator_rounds_like_astype_float32():
     m, n = 70, 333
     scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
