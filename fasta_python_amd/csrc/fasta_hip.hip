@@ -152,6 +152,7 @@ struct fh_ctx {
   double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
   double* hscal = nullptr;           // pinned, device-mapped host block: single-GPU launches write their scalars here
   double* hscal_dev = nullptr;       // device-side address of hscal
+  bool scal_mirrored = false;        // row-sharded runs: the last launch already copied the scalar block into hscal
   // tuning
   int fwd_rows = 0;          // 0 = auto
   long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
@@ -274,7 +275,9 @@ __global__ void k_forward_scalars(const double* src, double* dst) {
 }
 
 static int fetch_scalars(fh_ctx* c, double* scalars) {
-  if (c->comm) {
+  const bool mirrored = c->scal_mirrored;
+  c->scal_mirrored = false;
+  if (c->comm && !mirrored) {
     k_forward_scalars<<<dim3(1), dim3(64), 0, c->stream>>>(c->dscal, c->hscal_dev);
     HIP_TRY(hipGetLastError());
   }
@@ -758,7 +761,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
 }
 
 // n-side epilogue as its own launch (row-sharded runs, after the all-reduce of g1)
-static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, const double* coef_src = nullptr) {
+static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, const double* coef_src = nullptr, const double* pack = nullptr) {
   AdjP p;
   memset(&p, 0, sizeof(p));
   p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.nv2 = p.ld2; p.n = (uint32_t)c->n;
@@ -768,7 +771,8 @@ static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, c
   FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
   p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
   t_begin(c, FH_K_AUX);
-  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src, coef_src);
+  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src, coef_src, pack, c->hscal_dev);
+  c->scal_mirrored = true;         // (always the last launch before the caller's fetch_scalars)
   t_end(c, FH_K_AUX);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1006,6 +1010,7 @@ struct FusedIO {
   // FISTA (zero-initialised = off): x1 = xp + c*(xp - xacc0), gradient at z + c*(z - zacc0), c = coef or 0 after a restart
   int accel = 0, restart = 0; double coef = 0.0;
   const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr; double* coef_out = nullptr;
+  double* pack = nullptr;      // row-sharded: where the launch appends its loss sums and timeout word (behind g1)
 };
 
 // after the synchronisation that follows a one-pass launch: a launch that timed out has left slots un-posted / un-armed
@@ -1032,6 +1037,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.px = make_prox(c, tau);
   p.px.kind = io.kind;
   p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
+  p.pack = io.pack;
   const unsigned grid = p.nteams * sh.team;
   const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);     // (32 members: four 64-byte lines per row)   // whole 64-byte lines; + one line per team for the restart dot
   const size_t gpart_elems = (size_t)p.nteams * p.nv2 * 2;
@@ -1430,23 +1436,22 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
   if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
   const bool sharded = c->comm != nullptr;
   double* g1 = c->G[c->gc ^ 1];
-  const FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], g1, c->prox_kind, sharded ? 2 : 0};
+  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], g1, c->prox_kind, sharded ? 2 : 0};
+  double* pack = g1 + c->nv;                   // slack behind every n-side vector (alloc_vectors)
+  if (sharded) fio.pack = pack;
   FH_TRY(launch_fused_dense(c, tau, fio));
   c->last_accel = false;
   if (sharded) {
+    // ONE collective per iteration: g1 with the local loss sum and the timeout word appended (every rank then sees the same
+    // verdict, so all of them drop to the two-launch path together if a hand-off ever times out)
     t_begin(c, FH_K_COMM);
-    NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    // the timeout word too: every rank then sees the same verdict, so all of them drop to the two-launch path together
-    NCCL_TRY(g_rccl.AllReduce(c->dscal + 15, c->dscal + 15, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv + 3, kNcclFloat64, kNcclSum, c->comm, c->stream));
     t_end(c, FH_K_COMM);
     AdjIO io;
     io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 0; io.coef = 0.0; io.mode = 0; io.tau = tau;
     io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
     io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
-    FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ));
+    FH_TRY(bb_epilogue_only(c, io, pack, nullptr, pack));
   }
   FH_TRY(fetch_scalars(c, scalars));
   fused_after(c);
@@ -1486,22 +1491,19 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
   fio.accel = 1; fio.restart = restart ? 1 : 0; fio.coef = coef;
   fio.xacc0 = c->P[c->pc]; fio.zacc0 = c->Z[c->zc]; fio.x1 = c->X[c->ti];
   fio.coef_out = sharded ? coef_dev : nullptr;
+  double* pack = g1 + c->nv;
+  if (sharded) fio.pack = pack;
   FH_TRY(launch_fused_dense(c, tau, fio));
   c->last_accel = true;
   if (sharded) {
     t_begin(c, FH_K_COMM);
-    NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ_ADJ, c->dscal + FH_S_FSQ_ADJ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllReduce(c->dscal + 15, c->dscal + 15, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));   // shared timeout verdict
-    NCCL_TRY(g_rccl.GroupEnd());
+    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv + 3, kNcclFloat64, kNcclSum, c->comm, c->stream));   // g1 + loss sums + timeout word
     t_end(c, FH_K_COMM);
     AdjIO io;
     io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 1; io.coef = coef; io.mode = 0; io.tau = tau;
     io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
     io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
-    FH_TRY(bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ, coef_dev));
+    FH_TRY(bb_epilogue_only(c, io, pack + 2, coef_dev, pack));
   }
   FH_TRY(fetch_scalars(c, scalars));
   fused_after(c);

@@ -344,7 +344,11 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 
 // n-side epilogue as its own launch: used after the RCCL all-reduce when A is row-sharded
 // (g1 already holds the global sum).  grid = nchunks workgroups of 256 column pairs.
-__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t nchunks, const double* fsq_src, const double* coef_src) {
+// `pack` (optional): the 3 doubles a one-pass launch appended to g1 and the all-reduce summed over the ranks (loss sum, timeout
+// word, loss sum at the extrapolated point).  `mirror` (optional): host-mapped copy of the complete scalar block, written by the
+// finalising thread so that the caller needs no further launch to see it.
+__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t nchunks, const double* fsq_src, const double* coef_src,
+                                                       const double* pack, double* mirror) {
   AdjP p = p_in;
   if (coef_src) p.coef = *coef_src;      // FISTA coefficient decided on the device by the one-pass kernel (restart rule)
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
@@ -383,6 +387,11 @@ __global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t
     p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
     p.out[S_GSUM_ADJ] = w[3]; p.out[S_GMAX_ADJ] = w[4];
     p.out[S_FSQ_ADJ] = *fsq_src;
+    if (pack) { p.out[S_FSQ] = pack[0]; p.out[15] = pack[1]; }
+    if (mirror) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mirror[k] = p.out[k];
+    }
     __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

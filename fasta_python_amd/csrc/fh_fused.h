@@ -98,6 +98,8 @@ struct FusedP {
   double coef;
   const double* xacc0; const double* zacc0; double* x1;
   double* coef_out;      // optional: the coefficient actually applied (for the separate n-side epilogue of row-sharded runs)
+  double* pack;          // optional (row-sharded runs): 3 doubles behind g1 -- local loss sum, timeout word, loss sum at the extrapolated
+                         // point -- so that ONE all-reduce of g1 carries them along
   double* slots;         // [mp + nteams][max(TEAM, 8)] partial dot products (last nteams lines: restart dot), holding the sentinel on entry
   double* slots_next;    // the same array of the NEXT launch: every slot this launch posts is re-armed there with the sentinel, so
                          // no launch needs a host-side refill (two arrays alternate; the host refills both only when the shape changes)
@@ -608,7 +610,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = p.accel ? a[7] : a[0];
       p.out[S_ALPHA] = level;
       if (p.coef_out) *p.coef_out = coef;
-      p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
+      const double timed_out = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
+      p.out[15] = timed_out;
+      if (p.pack) { p.pack[0] = a[0]; p.pack[1] = timed_out; p.pack[2] = p.accel ? a[7] : a[0]; }
       // leave the counters zero for the next launch (every workgroup is past the grid barrier and has taken its final ticket)
       __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
