@@ -190,6 +190,12 @@ enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_E
 
 static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 
+// device scratch that is released on every exit path (the HIP_TRY macros return early)
+struct DevBuf {
+  double* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 static int use_device(fh_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   return 0;
@@ -295,12 +301,7 @@ extern "C" int fh_device_count(int* count) {
   return 0;
 }
 
-extern "C" int fh_create(int device, fh_ctx** out) {
-  if (!out) return fail(FH_E_ARG, "fh_create: null out pointer");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev) return fail(FH_E_ARG, "fh_create: device %d out of range (have %d)", device, ndev);
-  fh_ctx* c = new fh_ctx();
+static int create_body(fh_ctx* c, int device) {
   c->device = device;
   HIP_TRY(hipSetDevice(device));
   (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // spin on stream syncs: the host waits ~2x per iteration
@@ -319,6 +320,26 @@ extern "C" int fh_create(int device, fh_ctx** out) {
     HIP_TRY(hipEventCreate(&c->ev[k][1]));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int fh_destroy(fh_ctx* c);
+
+extern "C" int fh_create(int device, fh_ctx** out) {
+  if (!out) return fail(FH_E_ARG, "fh_create: null out pointer");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(FH_E_ARG, "fh_create: device %d out of range (have %d)", device, ndev);
+  fh_ctx* c = new fh_ctx();
+  for (int k = 0; k < FH_NKERNELS; ++k) c->ev[k][0] = c->ev[k][1] = nullptr;
+  const int rc = create_body(c, device);
+  if (rc != 0) {                                     // release whatever was created (the error text is already set)
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    (void)fh_destroy(c);
+    memcpy(g_err, keep, sizeof(keep));
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -338,14 +359,14 @@ extern "C" int fh_comm_destroy(fh_ctx* c);
 extern "C" int fh_destroy(fh_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)fh_comm_destroy(c);
   free_operator(c);
   if (c->counters) (void)hipFree(c->counters);
   if (c->dscal) (void)hipFree(c->dscal);
   if (c->hscal) (void)hipHostFree(c->hscal);
-  for (int k = 0; k < FH_NKERNELS; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
-  (void)hipStreamDestroy(c->stream);
+  for (int k = 0; k < FH_NKERNELS; ++k) { if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]); if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]); }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -426,8 +447,9 @@ extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n,
   }
   // float32 storage: float64 row blocks go through a staging buffer and are rounded on the device (round to nearest even)
   const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(m, ((uint64_t)64 << 20) / (n * sizeof(double))));
-  double* stage = nullptr;
-  HIP_TRY(hipMalloc((void**)&stage, chunk * n * sizeof(double)));
+  DevBuf staging;
+  HIP_TRY(hipMalloc((void**)&staging.p, chunk * n * sizeof(double)));
+  double* stage = staging.p;
   for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
     const uint64_t rows = std::min<uint64_t>(chunk, m - r0);
     HIP_TRY(hipMemcpy2DAsync(stage, n * sizeof(double), A + r0 * ld_host, ld_host * sizeof(double), n * sizeof(double), rows,
@@ -436,7 +458,6 @@ extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));      // the host block may be pageable: finish before the next chunk reuses `stage`
   }
-  (void)hipFree(stage);
   return finish(c);
 }
 
@@ -474,8 +495,9 @@ extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, doub
   }
   // float32 storage: widen on the device (exact), row blocks through a staging buffer
   const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nrows, ((uint64_t)64 << 20) / (c->n * sizeof(double))));
-  double* stage = nullptr;
-  HIP_TRY(hipMalloc((void**)&stage, chunk * c->n * sizeof(double)));
+  DevBuf staging;
+  HIP_TRY(hipMalloc((void**)&staging.p, chunk * c->n * sizeof(double)));
+  double* stage = staging.p;
   for (uint64_t r0 = 0; r0 < nrows; r0 += chunk) {
     const uint64_t rows = std::min<uint64_t>(chunk, nrows - r0);
     k_rows_from_f32<<<dim3(2048), dim3(FH_WG), 0, c->stream>>>(reinterpret_cast<const float*>(c->A) + (row0 + r0) * c->ld, c->ld, stage, c->n, (uint32_t)rows, (uint32_t)c->n);
@@ -483,7 +505,6 @@ extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, doub
     HIP_TRY(hipMemcpyAsync(out + r0 * c->n, stage, rows * c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
-  (void)hipFree(stage);
   return finish(c);
 }
 
