@@ -478,7 +478,7 @@ def main(argv=None):
             extra["lasso_two_launch"] = sub_result(r, f"LASSO {m_total}x{n}, two launches per iteration (K-fwd + K-adj, the north-star structure)")
         r = run_dense(args, grp, A, m_total, n, "nnls", fused, args.steps, args.warmup)
         extra["nnls"] = sub_result(r, f"NNLS {m_total}x{n} (BASELINE config 3), non-negativity prox, same matrix")
-        if grp.world > 1:
+        if grp.world > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
             # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
             A.close()
             A = shard(32768 * grp.world)
