@@ -16,7 +16,8 @@ anything touches HIP) and relay rank 0's line.
 Prints ONE JSON line (rank 0): the driver's contract fields, `roofline` (achieved = the bytes the EXECUTED
 algorithm must move / the dominant kernel's HIP-event time, so frac <= 1), `cpu_baseline`, and `extra`:
 the other BASELINE configs timed by the same code in the same process -- nnls (config 3), tv and
-tv_accelerated (config 4), lasso_two_launch (the two-launch structure), and for N > 1 `config5_shard`
+tv_accelerated (config 4), lasso_two_launch (the two-launch structure), lasso_f32_storage (opt-in float32 storage of A),
+lasso_wide_131072 (the widest single-team-of-16 shape), and for N > 1 `config5_shard`
 (32768 rows per rank = BASELINE config 5's per-GPU shape).
 """
 import argparse
@@ -500,6 +501,16 @@ def main(argv=None):
             s32["tolerance"] = ("iterates equal the reference's run on A.astype(float32) to the float64 path's tolerances; against the "
                                 "float64-matrix run they differ by the rounding of A (<= 3e-7 relative away from the chaotic regime)")
             extra["lasso_f32_storage"] = s32
+            # wide rows (n in (65536, 131072]: x slice in LDS, posting one row ahead): 32768 x 131072, the same 32 GiB
+            if (m_total, n) == (65536, 65536):
+                Aw = fa.DenseMatrixMap.synthetic(32768, 131072, seed=0, scale=synthetic.lasso_scale(32768, 131072), device=grp.local_rank)
+                try:
+                    r = run_dense(args, grp, Aw, 32768, 131072, "lasso", fused, args.steps, args.warmup)
+                    s = sub_result(r, "LASSO 32768x131072 float64 (wide rows: 16 members x 16 pieces, x slice in LDS)")
+                    s["fused_supported"] = Aw.ctx.fused_supported()
+                    extra["lasso_wide_131072"] = s
+                finally:
+                    Aw.close()
             for key, acc in (("tv", False), ("tv_accelerated", True)):
                 r = run_tv(args, grp, args.steps, args.warmup, "auto", acc)
                 s = sub_result(r, f"TV denoising {args.image}x{args.image} (BASELINE config 4), "
