@@ -7,11 +7,13 @@ and `Convergence` record (reference: fasta/__init__.py:38-53, :323-351); the wor
 hand-written HIP kernels through the ctypes C ABI of include/fasta_hip.h.  The top-level `fasta`
 package in this repository re-exports these names so `import fasta` keeps working.
 
-No CPU fallback: importing works anywhere, but creating an operator or calling `fasta()` needs the
-built `libfasta_hip.so` and a gfx950 GPU, and raises otherwise.
+Which loop runs is decided by the operand types: device-recognisable operands (matrix / DenseMatrixMap / GradDivMap + tagged
+loss + tagged prox) run the HIP loop and raise when the built `libfasta_hip.so` or a gfx950 GPU is missing -- no CPU fallback;
+closures, callable pairs, `A=None` and host LinearMaps cannot execute inside a kernel and run the generic host loop
+(`generic.py`, the reference's semantics).  `backend="hip"` / `backend="numpy"` force either.
 """
 
-from . import hip, linalg, losses, proximal, stopping
+from . import generic, hip, linalg, losses, proximal, stopping
 from .linalg import DenseMatrixMap, GradDivMap, LinearMap, LinearOperator
 from .losses import LeastSquares, LogisticLoss
 from .proximal import Box, L1Ball, LinfProx, NonNeg, NoProx, Shrink, TVDualBall

@@ -1,7 +1,7 @@
 """ctypes binding of libfasta_hip.so (C ABI: include/fasta_hip.h).
 
-This is the only module that talks to the GPU.  There is no CPU fallback anywhere in the package:
-if the shared library is missing or no MI355X is visible, `load_library()` / `HipContext()` raise.
+This is the only module that talks to the GPU, and nothing in it falls back: if the shared library is missing or
+no MI355X is visible, `load_library()` / `HipContext()` raise.
 """
 
 import ctypes as C
