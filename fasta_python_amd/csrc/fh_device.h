@@ -55,15 +55,30 @@ struct ProxP {
   const double* level; // LINF / L1BALL: device scalar holding the clipping level alpha
 };
 
+// Cross-lane reductions by DPP (VALU) instead of `__shfl_down` (ds_bpermute: an LDS-crossbar round trip of ~100 cycles per step,
+// six dependent steps, twice per double): every lane ends up with the wave's result, in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // lane 0 holds the sum
+  v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);      // row_half_mirror
+  v += dpp_f64<0x140>(v);      // row_mirror: every lane of a 16-lane row holds the row's sum
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-  return v;
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // sign(x) as NumPy defines it for finite x (np.sign): -1, 0 or +1

@@ -51,24 +51,9 @@
 // for the LDS traffic only and leaves the row loads in flight.
 __device__ __forceinline__ void ft_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Cross-lane sums without LDS round trips (the row loop's serial chain is dot -> wave sum -> barrier -> exchange ->
-// barrier -> update; `__shfl_down` lowers to ds_bpermute, ~100 cycles per step and six dependent steps per row).
-template <int CTRL>
-__device__ __forceinline__ double ft_dpp(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double ft_readlane(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double ft_wave_sum(double v) {       // every lane gets the same sum (fixed order)
-  v += ft_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
-  v += ft_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
-  v += ft_dpp<0x141>(v);      // row_half_mirror
-  v += ft_dpp<0x140>(v);      // row_mirror: every lane of a 16-lane row holds the row's sum
-  return ((ft_readlane(v, 0) + ft_readlane(v, 16)) + ft_readlane(v, 32)) + ft_readlane(v, 48);
-}
+// Cross-lane sums without LDS round trips (the row loop's serial chain is dot -> wave sum -> barrier -> exchange -> barrier ->
+// update): the DPP reduction of fh_device.h, every lane gets the same sum (fixed order).
+__device__ __forceinline__ double ft_wave_sum(double v) { return wave_sum(v); }
 
 // -DFT_PROFILE: wave 0 of block 0 accumulates s_memtime ticks per phase of the row loop and prints them (debug builds only)
 #ifdef FT_PROFILE
