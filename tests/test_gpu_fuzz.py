@@ -111,9 +111,10 @@ def test_random_stencil_shapes_and_modes(seed):
     opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=25, tolerance=0.0, evaluate_objective=bool(seed % 3),
                 record_iterates=bool(seed % 2), restart=bool((seed // 2) % 2), window=int(rng.randint(1, 12)))
     P = pr.tv_denoising_from(M, mu)
+    no_prox = seed in (3, 8)                   # g = None: plain gradient descent on the stencil operator (fasta/__init__.py:88-90)
     op = fa.GradDivMap((H_, W_))
     try:
-        ls, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        ls, reg = fa.LeastSquares(M / mu), (fa.NoProx() if no_prox else fa.TVDualBall())
         solver = fa.FBSolver(op, ls, reg, Y0, verbose=False, **opts)
         np.random.seed(seed)
         got = solver.setup().run()
@@ -123,7 +124,7 @@ def test_random_stencil_shapes_and_modes(seed):
     np.random.seed(seed)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, Y0, **opts)
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, None if no_prox else P.g, None if no_prox else P.proxg, Y0, **opts)
     _same(got, want)
     if opts["record_iterates"]:
         np.testing.assert_allclose(got.iterates, want.iterates, rtol=1e-5, atol=1e-9)
