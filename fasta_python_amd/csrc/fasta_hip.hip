@@ -16,6 +16,21 @@
 #include "fh_prox.h"
 #include "fh_fused.h"
 
+// the one-pass kernel's variants are compiled in fh_fused_part.hip (four groups, in parallel): here they are only declared
+// (-DFH_SINGLE_TU, used by the asm / resources / prof targets, instantiates everything in this unit instead)
+#ifndef FH_SINGLE_TU
+#define FH_FUSED_DECLARE(P, PI, T, X, NB, F) extern template __global__ void k_fused_dense<P, 1, PI, T, X, NB, F>(const FusedP);
+#define FUSED_INST_0 FH_FUSED_DECLARE
+#define FUSED_INST_1 FH_FUSED_DECLARE
+#define FUSED_INST_2 FH_FUSED_DECLARE
+#define FUSED_INST_3 FH_FUSED_DECLARE
+#include "fh_fused_instances.inc"
+#undef FUSED_INST_0
+#undef FUSED_INST_1
+#undef FUSED_INST_2
+#undef FUSED_INST_3
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
 // `pack` (optional): the 3 doubles a one-pass launch appended to g1 and the all-reduce summed over the ranks (loss sum, timeout
 // word, loss sum at the extrapolated point).  `mirror` (optional): host-mapped copy of the complete scalar block, written by the
 // finalising thread so that the caller needs no further launch to see it.
-__global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t nchunks, const double* fsq_src, const double* coef_src,
+static __global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t nchunks, const double* fsq_src, const double* coef_src,
                                                        const double* pack, double* mirror) {
   AdjP p = p_in;
   if (coef_src) p.coef = *coef_src;      // FISTA coefficient decided on the device by the one-pass kernel (restart rule)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(FH_WG) void k_bb_epilogue(const AdjP p_in, uint32_t
   }
 }
 
-// ---- utility kernels ---------------------------------------------------------------------------
+// ---- utility kernels (non-template kernels are `static`: this header is included by several translation units) ------------
 template <int F32>
 __global__ __launch_bounds__(FH_WG) void k_gen_matrix(double* A, uint32_t ld2, uint32_t m, uint32_t mp,
                                                       uint32_t n, uint64_t row0, uint64_t key, double coef) {
@@ -420,13 +420,13 @@ __global__ __launch_bounds__(FH_WG) void k_gen_matrix(double* A, uint32_t ld2, u
 }
 
 // float64 rows <-> float32 storage (fh_set_matrix / fh_get_matrix_rows in float32-storage mode), `rows` x `n` elements
-__global__ __launch_bounds__(FH_WG) void k_rows_to_f32(const double* src, uint64_t src_ld, float* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
+static __global__ __launch_bounds__(FH_WG) void k_rows_to_f32(const double* src, uint64_t src_ld, float* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
   for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < (uint64_t)rows * n; t += (uint64_t)gridDim.x * FH_WG) {
     const uint64_t r = t / n, c = t % n;
     dst[r * dst_ld + c] = (float)src[r * src_ld + c];
   }
 }
-__global__ __launch_bounds__(FH_WG) void k_rows_from_f32(const float* src, uint64_t src_ld, double* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
+static __global__ __launch_bounds__(FH_WG) void k_rows_from_f32(const float* src, uint64_t src_ld, double* dst, uint64_t dst_ld, uint32_t rows, uint32_t n) {
   for (uint64_t t = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; t < (uint64_t)rows * n; t += (uint64_t)gridDim.x * FH_WG) {
     const uint64_t r = t / n, c = t % n;
     dst[r * dst_ld + c] = (double)src[r * src_ld + c];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(FH_WG) void k_rows_from_f32(const float* src, uint6
 }
 
 // sum of (a-b)^2 over len elements -> out[0]; single-workgroup-final pattern
-__global__ __launch_bounds__(FH_WG) void k_diff_sq(const double* a, const double* b, uint32_t len, double* red,
+static __global__ __launch_bounds__(FH_WG) void k_diff_sq(const double* a, const double* b, uint32_t len, double* red,
                                                    unsigned* counter, double* out) {
   __shared__ __attribute__((aligned(16))) double s_scr[4];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(FH_WG) void k_diff_sq(const double* a, const double
 }
 
 // sum|x| and max|x| over len elements -> out[S_GSUM], out[S_GMAX]
-__global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len, double* red, unsigned* counter, double* out) {
+static __global__ __launch_bounds__(FH_WG) void k_gterms(const double* x, uint32_t len, double* red, unsigned* counter, double* out) {
   __shared__ __attribute__((aligned(16))) double s_scr[8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   double v[2] = {0.0, 0.0};
