@@ -3,7 +3,7 @@
 #include "fh_fused.h"
 
 #ifndef FH_PART
-#error "compile with -DFH_PART=<group>"
+#define FH_PART 0          // a bare `hipcc -c fh_fused_part.hip` builds group 0
 #endif
 #define FH_FUSED_DEFINE(P, PI, T, X, NB, F) template __global__ void k_fused_dense<P, 1, PI, T, X, NB, F>(const FusedP);
 #if FH_PART == 0
