@@ -14,11 +14,11 @@ closures, callable pairs, `A=None` and host LinearMaps cannot execute inside a k
 """
 
 from . import generic, hip, linalg, losses, proximal, stopping
-from .linalg import DenseMatrixMap, GradDivMap, LinearMap, LinearOperator
+from .linalg import DenseMatrixMap, GradDivMap, LinearMap, LinearOperator, ShardedDenseMatrixMap
 from .losses import LeastSquares, LogisticLoss
 from .proximal import Box, L1Ball, LinfProx, NonNeg, NoProx, Shrink, TVDualBall
 from .solver import EPSILON, Convergence, FBSolver, fasta
 
 __all__ = ["fasta", "Convergence", "FBSolver", "EPSILON", "linalg", "proximal", "stopping", "losses", "hip",
-           "LinearMap", "LinearOperator", "DenseMatrixMap", "GradDivMap", "LeastSquares", "LogisticLoss",
+           "LinearMap", "LinearOperator", "DenseMatrixMap", "ShardedDenseMatrixMap", "GradDivMap", "LeastSquares", "LogisticLoss",
            "Shrink", "NonNeg", "LinfProx", "L1Ball", "Box", "TVDualBall", "NoProx"]

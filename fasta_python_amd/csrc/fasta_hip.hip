@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 
 #include "../../include/fasta_hip.h"
 #include "fh_dense.h"
@@ -68,6 +69,7 @@ struct RcclApi {
   void* lib = nullptr;
   int (*GetUniqueId)(fh_nccl_uid*) = nullptr;
   int (*CommInitRank)(fh_nccl_comm*, int, fh_nccl_uid, int) = nullptr;
+  int (*CommInitAll)(fh_nccl_comm*, int, const int*) = nullptr;
   int (*CommDestroy)(fh_nccl_comm) = nullptr;
   int (*CommCount)(const fh_nccl_comm, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, fh_nccl_comm, hipStream_t) = nullptr;
@@ -92,6 +94,7 @@ static int rccl_load() {
   if (!g_rccl.field) return fail(FH_E_RCCL, "librccl lacks symbol %s", name)
   SYM(GetUniqueId, "ncclGetUniqueId");
   SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommInitAll, "ncclCommInitAll");
   SYM(CommDestroy, "ncclCommDestroy");
   SYM(CommCount, "ncclCommCount");
   SYM(AllReduce, "ncclAllReduce");
@@ -180,6 +183,7 @@ struct fh_ctx {
   int tv_u = 0;              // 0 = auto: 8 for the kernels that stream z, 2 / 4 for the z-free one-pass sweeps (profiles/r02_tune_tv.txt)
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
+  int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
   int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
   // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
@@ -198,7 +202,25 @@ struct fh_ctx {
   fh_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
   int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
+  // ---- in-process row sharding (fh_create_ex with ndev > 1; SURVEY.md 8(b)/(e): one host thread, one context per device) ----
+  // A context created over several devices is a SHELL: it owns one child context per entry of dev_ids (`shards`), each holding
+  // a contiguous block of rows of A and the matching slice of b / z, while x, g, xhat are replicated.  Every entry point of the
+  // C ABI runs on a shell as: local launches on every shard -> sum over the shards -> n-side epilogue on every shard -> ONE host
+  // synchronisation, scalars from shard 0.  The sum is one grouped ncclAllReduce per shard (communicators from
+  // ncclCommInitAll) when the device ids differ; when they REPEAT (several shards on one GPU: what a one-GPU box can run) all
+  // shards share one stream and k_sum_shards adds their buffers in shard order.
+  std::vector<fh_ctx*> shards;       // non-empty: this context is a shell
+  std::vector<uint64_t> shard_row0;  // first row of every shard, plus the total (size shards + 1)
+  fh_ctx* owner = nullptr;           // set in a shard
+  bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)
+  bool owns_stream = true;           // false in shards 1.. of an emulated group (they run on shard 0's stream)
 };
+
+#define FH_MAX_SHARDS 64
+static inline int nshards(fh_ctx* c) { return c->shards.empty() ? 1 : (int)c->shards.size(); }
+static inline fh_ctx* shard_of(fh_ctx* c, int k) { return c->shards.empty() ? c : c->shards[k]; }
+// a context whose launches leave the sums over rows to an exchange step: a rank of a multi-process run, or a shard of a shell
+static inline bool row_sharded(const fh_ctx* c) { return c->comm != nullptr || c->owner != nullptr; }
 
 static const int kCounterWords = 8192;
 enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_ADJ_CC = 16 };
@@ -217,6 +239,7 @@ static int use_device(fh_ctx* c) {
 }
 
 static void free_operator(fh_ctx* c) {
+  for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); free_operator(s); }
   auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   fr(c->A);
   for (int i = 0; i < 2; ++i) { fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
@@ -271,6 +294,10 @@ static inline void t_end(fh_ctx* c, int k) {
   if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
 }
 static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending event pairs
+  if (!c->shards.empty()) {        // shell: all shards (an emulated group shares one stream; its first shard's sync covers the rest)
+    for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); FH_TRY(finish(s)); }
+    return 0;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->timing) {
     for (int k = 0; k < FH_NKERNELS; ++k) {
@@ -287,7 +314,7 @@ static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending e
 
 // Where kernels write the FH_S_* block: straight into the mapped host block on one GPU (no D2H copy, the
 // stream sync alone publishes it); device memory when row-sharded, because RCCL reduces scalars in place.
-static inline double* scalar_out(fh_ctx* c) { return c->comm ? c->dscal : c->hscal_dev; }
+static inline double* scalar_out(fh_ctx* c) { return row_sharded(c) ? c->dscal : c->hscal_dev; }
 
 // row-sharded runs: the block lives in device memory (RCCL reduces into it); a 16-lane kernel forwards it to the mapped
 // host block -- a hipMemcpyAsync D2H of 128 bytes costs ~10 us more per iteration than this launch
@@ -296,15 +323,82 @@ __global__ void k_forward_scalars(const double* src, double* dst) {
 }
 
 static int fetch_scalars(fh_ctx* c, double* scalars) {
-  const bool mirrored = c->scal_mirrored;
-  c->scal_mirrored = false;
-  if (c->comm && !mirrored) {
-    k_forward_scalars<<<dim3(1), dim3(64), 0, c->stream>>>(c->dscal, c->hscal_dev);
-    HIP_TRY(hipGetLastError());
+  for (int k = 0; k < nshards(c); ++k) {
+    fh_ctx* s = shard_of(c, k);
+    const bool mirrored = s->scal_mirrored;
+    s->scal_mirrored = false;
+    if (row_sharded(s) && !mirrored) {
+      HIP_TRY(hipSetDevice(s->device));
+      k_forward_scalars<<<dim3(1), dim3(64), 0, s->stream>>>(s->dscal, s->hscal_dev);
+      HIP_TRY(hipGetLastError());
+    }
   }
-  FH_TRY(finish(c));
-  if (scalars) memcpy(scalars, c->hscal, FH_NSCALARS * sizeof(double));
+  FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
+  // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors
+  if (scalars) memcpy(scalars, shard_of(c, 0)->hscal, FH_NSCALARS * sizeof(double));
   return 0;
+}
+
+// ---- sums over the row blocks ------------------------------------------------------------------------------------------
+// out[i] = ((v0[i] + v1[i]) + v2[i]) + ... written back to every shard's buffer: the in-library, fixed-order replacement for the
+// all-reduce when several shards live on ONE device (device ids repeat; all shards share a stream, so plain ordering suffices)
+struct SumShardsP { double* v[FH_MAX_SHARDS]; int n; };
+__global__ __launch_bounds__(FH_WG) void k_sum_shards(const SumShardsP p, uint64_t count) {
+  for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < count; i += (uint64_t)gridDim.x * FH_WG) {
+    double acc = p.v[0][i];
+    for (int k = 1; k < p.n; ++k) acc += p.v[k][i];
+    for (int k = 0; k < p.n; ++k) p.v[k][i] = acc;
+  }
+}
+
+// Sum `count` doubles at sel(shard) -- and, in the same exchange, `count2` doubles at sel2(shard) -- over all row blocks, in place,
+// on every shard:
+//   plain context with a communicator (one process per GPU) -> ncclAllReduce on its stream;
+//   shell over distinct devices -> one grouped ncclAllReduce per shard (ncclCommInitAll communicators, one host thread);
+//   shell over a repeated device -> k_sum_shards;      plain context without a communicator -> nothing to do.
+template <typename Sel, typename Sel2>
+static int sum_over_shards(fh_ctx* c, Sel sel, size_t count, Sel2 sel2, size_t count2) {
+  if (c->shards.empty()) {
+    if (!c->comm) return 0;
+    t_begin(c, FH_K_COMM);
+    if (count2) NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllReduce(sel(c), sel(c), count, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    if (count2) {
+      NCCL_TRY(g_rccl.AllReduce(sel2(c), sel2(c), count2, kNcclFloat64, kNcclSum, c->comm, c->stream));
+      NCCL_TRY(g_rccl.GroupEnd());
+    }
+    t_end(c, FH_K_COMM);
+    return 0;
+  }
+  if (c->emulated) {
+    fh_ctx* s0 = c->shards[0];
+    HIP_TRY(hipSetDevice(s0->device));
+    t_begin(s0, FH_K_COMM);
+    for (int pass = 0; pass < (count2 ? 2 : 1); ++pass) {
+      SumShardsP sp;
+      sp.n = (int)c->shards.size();
+      for (int k = 0; k < sp.n; ++k) sp.v[k] = pass ? sel2(c->shards[k]) : sel(c->shards[k]);
+      const uint64_t cnt = pass ? count2 : count;
+      const unsigned grid = (unsigned)std::min<uint64_t>((cnt + FH_WG - 1) / FH_WG, 1024);
+      k_sum_shards<<<dim3(grid), dim3(FH_WG), 0, s0->stream>>>(sp, cnt);
+    }
+    t_end(s0, FH_K_COMM);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_begin(s, FH_K_COMM); }
+  NCCL_TRY(g_rccl.GroupStart());
+  for (fh_ctx* s : c->shards) {
+    NCCL_TRY(g_rccl.AllReduce(sel(s), sel(s), count, kNcclFloat64, kNcclSum, s->comm, s->stream));
+    if (count2) NCCL_TRY(g_rccl.AllReduce(sel2(s), sel2(s), count2, kNcclFloat64, kNcclSum, s->comm, s->stream));
+  }
+  NCCL_TRY(g_rccl.GroupEnd());
+  for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_end(s, FH_K_COMM); }
+  return 0;
+}
+template <typename Sel>
+static int sum_over_shards(fh_ctx* c, Sel sel, size_t count) {
+  return sum_over_shards(c, sel, count, [](fh_ctx*) { return (double*)nullptr; }, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -316,12 +410,13 @@ extern "C" int fh_device_count(int* count) {
   return 0;
 }
 
-static int create_body(fh_ctx* c, int device) {
+static int create_body(fh_ctx* c, int device, hipStream_t shared_stream = nullptr) {
   c->device = device;
   HIP_TRY(hipSetDevice(device));
   (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // spin on stream syncs: the host waits ~2x per iteration
   (void)hipGetLastError();
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (shared_stream) { c->stream = shared_stream; c->owns_stream = false; }     // shards 1.. of a group on one device
+  else HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); c->ncu = prop.multiProcessorCount; }
   HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
@@ -340,32 +435,78 @@ static int create_body(fh_ctx* c, int device) {
 
 extern "C" int fh_destroy(fh_ctx* c);
 
-extern "C" int fh_create(int device, fh_ctx** out) {
-  if (!out) return fail(FH_E_ARG, "fh_create: null out pointer");
+// destroys a partially built context while keeping the error text of what failed
+static int create_failed(fh_ctx* c, int rc) {
+  char keep[sizeof(g_err)];
+  memcpy(keep, g_err, sizeof(keep));
+  (void)fh_destroy(c);
+  memcpy(g_err, keep, sizeof(keep));
+  return rc;
+}
+
+static int create_one(int device, hipStream_t shared_stream, fh_ctx** out) {
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(FH_E_ARG, "fh_create: device %d out of range (have %d)", device, ndev);
   fh_ctx* c = new fh_ctx();
   for (int k = 0; k < FH_NKERNELS; ++k) c->ev[k][0] = c->ev[k][1] = nullptr;
-  const int rc = create_body(c, device);
-  if (rc != 0) {                                     // release whatever was created (the error text is already set)
-    char keep[sizeof(g_err)];
-    memcpy(keep, g_err, sizeof(keep));
-    (void)fh_destroy(c);
-    memcpy(g_err, keep, sizeof(keep));
-    return rc;
-  }
+  const int rc = create_body(c, device, shared_stream);
+  if (rc != 0) return create_failed(c, rc);          // release whatever was created (the error text is already set)
   *out = c;
   return 0;
 }
 
-// SURVEY.md 8(b) form of the constructor: device list + storage type of A.  One process drives one GPU in this design
-// (row sharding = one context per process + RCCL), so ndev must be 1.
+extern "C" int fh_create(int device, fh_ctx** out) {
+  if (!out) return fail(FH_E_ARG, "fh_create: null out pointer");
+  return create_one(device, nullptr, out);
+}
+
+// SURVEY.md 8(b) form of the constructor: device list + storage type of A.
+//   ndev == 1: a plain context (as fh_create; one process per GPU attaches it to a communicator with fh_comm_init).
+//   ndev  > 1: IN-PROCESS row sharding -- a shell over one shard per entry of dev_ids.  Distinct ids: one GPU each, RCCL
+//              communicators from ncclCommInitAll, grouped all-reduce.  A repeated id (all entries equal): every shard on that one
+//              GPU, one stream, sums by k_sum_shards in shard order -- the form a one-GPU box can run and test.
 extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out) {
-  if (ndev != 1 || !dev_ids) return fail(FH_E_ARG, "fh_create_ex: one device per context (got ndev = %d); row sharding uses one process per GPU and fh_comm_init", ndev);
+  if (!out || !dev_ids) return fail(FH_E_ARG, "fh_create_ex: null argument");
+  if (ndev < 1 || ndev > FH_MAX_SHARDS) return fail(FH_E_ARG, "fh_create_ex: ndev must be in [1,%d] (got %d)", FH_MAX_SHARDS, ndev);
   if (dtype != FH_DTYPE_F64 && dtype != FH_DTYPE_F32_STORAGE) return fail(FH_E_ARG, "fh_create_ex: unknown dtype %d", dtype);
-  FH_TRY(fh_create(dev_ids[0], out));
-  (*out)->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
+  if (ndev == 1) {
+    FH_TRY(fh_create(dev_ids[0], out));
+    (*out)->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
+    return 0;
+  }
+  bool distinct = true, equal = true;
+  for (int i = 0; i < ndev; ++i) {
+    if (dev_ids[i] != dev_ids[0]) equal = false;
+    for (int j = 0; j < i; ++j) if (dev_ids[i] == dev_ids[j]) distinct = false;
+  }
+  if (!distinct && !equal)
+    return fail(FH_E_ARG, "fh_create_ex: device ids must be all different (one GPU per shard, RCCL) or all equal (every shard on one GPU)");
+  fh_ctx* shell = new fh_ctx();
+  for (int k = 0; k < FH_NKERNELS; ++k) shell->ev[k][0] = shell->ev[k][1] = nullptr;
+  shell->device = dev_ids[0];
+  shell->emulated = equal;
+  shell->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
+  for (int i = 0; i < ndev; ++i) {
+    fh_ctx* s = nullptr;
+    const int rc = create_one(dev_ids[i], (equal && i > 0) ? shell->shards[0]->stream : nullptr, &s);
+    if (rc != 0) return create_failed(shell, rc);
+    s->owner = shell; s->emulated = equal; s->f32 = shell->f32;
+    s->nranks = ndev; s->rank = i;
+    shell->shards.push_back(s);
+  }
+  shell->ncu = shell->shards[0]->ncu;
+  if (distinct) {
+    int rc = rccl_load();
+    if (rc == 0) {
+      std::vector<fh_nccl_comm> comms((size_t)ndev, nullptr);
+      const int nr = g_rccl.CommInitAll(comms.data(), ndev, dev_ids);
+      if (nr != 0) rc = fail(20000 + nr, "ncclCommInitAll over %d devices failed: %s", ndev, g_rccl.GetErrorString(nr));
+      else for (int i = 0; i < ndev; ++i) shell->shards[i]->comm = comms[(size_t)i];
+    }
+    if (rc != 0) return create_failed(shell, rc);
+  }
+  *out = shell;
   return 0;
 }
 
@@ -373,27 +514,41 @@ extern "C" int fh_comm_destroy(fh_ctx* c);
 
 extern "C" int fh_destroy(fh_ctx* c) {
   if (!c) return 0;
+  if (!c->shards.empty()) {                         // shell: the shards in reverse order (shard 0 owns an emulated group's stream)
+    for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); if (s->stream) (void)hipStreamSynchronize(s->stream); }
+    for (size_t k = c->shards.size(); k-- > 0;) { c->shards[k]->owner = nullptr; (void)fh_destroy(c->shards[k]); }
+    c->shards.clear();
+    delete c;
+    return 0;
+  }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->owner = nullptr;
   (void)fh_comm_destroy(c);
   free_operator(c);
   if (c->counters) (void)hipFree(c->counters);
   if (c->dscal) (void)hipFree(c->dscal);
   if (c->hscal) (void)hipHostFree(c->hscal);
   for (int k = 0; k < FH_NKERNELS; ++k) { if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]); if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]); }
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
 
 extern "C" int fh_sync(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
-  FH_TRY(use_device(c));
+  if (c->shards.empty()) FH_TRY(use_device(c));
   return finish(c);
 }
 
+static int set_tuning_one(fh_ctx* c, int key, long long value);
 extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
   if (!c) return fail(FH_E_ARG, "null context");
+  for (fh_ctx* s : c->shards) FH_TRY(set_tuning_one(s, key, value));      // a shell forwards to every shard (and keeps a copy)
+  return set_tuning_one(c, key, value);
+}
+
+static int set_tuning_one(fh_ctx* c, int key, long long value) {
   switch (key) {
     case FH_TUNE_FWD_ROWS:
       if (value != 0 && value != 4 && value != 8 && value != 16) return fail(FH_E_ARG, "FWD_ROWS must be 0 (auto), 4, 8 or 16");
@@ -420,11 +575,15 @@ extern "C" int fh_set_tuning(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > 4096) return fail(FH_E_ARG, "TV_ROWS must be in [0,4096] (0 = auto)");
       c->tv_rows = (int)value; return 0;
     case FH_TUNE_TV_NT:
-      c->tv_nt = value ? 1 : 0; return 0;
+      if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_NT must be 0 (default), 1 (non-temporal loads and stores), 2 (non-temporal stores) or 3 (plain)");
+      c->tv_nt = (int)value; return 0;
+    case FH_TUNE_TV_PIPE:
+      if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_PIPE must be 0 (auto), 1 (load a trip, consume it) or 3 (three rotating trip buffers; 2 is taken as 3)");
+      c->tv_pipe = (int)value; return 0;
     case FH_TUNE_TV_ZFREE:
       c->tv_zfree = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_VARIANT:
-      c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h); bits 9-10: wide-row candidate
+      c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
@@ -450,9 +609,31 @@ static int setup_dense(fh_ctx* c, uint64_t m, uint64_t n) {
   return 0;
 }
 
+// Row blocks of a shell: contiguous, the first (m mod p) shards hold ceil(m/p) rows and the others floor(m/p) -- SURVEY.md 8(e)'s
+// ceil(m/p) blocks whenever p divides m, and never an empty shard otherwise.
+static int shell_partition(fh_ctx* c, uint64_t m, uint64_t n) {
+  const uint64_t p = c->shards.size();
+  if (m < p) return fail(FH_E_ARG, "a matrix of %llu rows cannot be split over %llu shards", (unsigned long long)m, (unsigned long long)p);
+  c->shard_row0.assign(p + 1, 0);
+  for (uint64_t k = 0; k < p; ++k) c->shard_row0[k + 1] = c->shard_row0[k] + m / p + (k < m % p ? 1 : 0);
+  c->m = m; c->n = n; c->op = OP_NONE; c->has_b = false;
+  return 0;
+}
+static void shell_adopt(fh_ctx* c) {        // after every shard holds its block
+  c->op = OP_DENSE;
+  c->mp = c->m; c->ld = c->shards[0]->ld; c->nv = c->shards[0]->nv; c->mv = c->m;
+}
+static inline uint64_t shard_rows(fh_ctx* c, int k) { return c->shard_row0[(size_t)k + 1] - c->shard_row0[(size_t)k]; }
+
 extern "C" int fh_set_matrix(fh_ctx* c, const double* A, uint64_t m, uint64_t n, uint64_t ld_host) {
   if (!c || !A) return fail(FH_E_ARG, "fh_set_matrix: null argument");
   if (ld_host < n) return fail(FH_E_ARG, "fh_set_matrix: ld_host %llu < n %llu", (unsigned long long)ld_host, (unsigned long long)n);
+  if (!c->shards.empty()) {          // shell: each shard copies its own row block H2D
+    FH_TRY(shell_partition(c, m, n));
+    for (int k = 0; k < nshards(c); ++k) FH_TRY(fh_set_matrix(c->shards[k], A + c->shard_row0[k] * ld_host, shard_rows(c, k), n, ld_host));
+    shell_adopt(c);
+    return 0;
+  }
   FH_TRY(setup_dense(c, m, n));
   HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double)), c->stream));
   if (!c->f32) {
@@ -481,6 +662,12 @@ extern "C" int fh_set_matrix_f32(fh_ctx* c, const float* A, uint64_t m, uint64_t
   if (!c || !A) return fail(FH_E_ARG, "fh_set_matrix_f32: null argument");
   if (!c->f32) return fail(FH_E_STATE, "fh_set_matrix_f32 needs a float32-storage context (fh_create_ex with FH_DTYPE_F32_STORAGE)");
   if (ld_host < n) return fail(FH_E_ARG, "fh_set_matrix_f32: ld_host %llu < n %llu", (unsigned long long)ld_host, (unsigned long long)n);
+  if (!c->shards.empty()) {
+    FH_TRY(shell_partition(c, m, n));
+    for (int k = 0; k < nshards(c); ++k) FH_TRY(fh_set_matrix_f32(c->shards[k], A + c->shard_row0[k] * ld_host, shard_rows(c, k), n, ld_host));
+    shell_adopt(c);
+    return 0;
+  }
   FH_TRY(setup_dense(c, m, n));
   HIP_TRY(hipMemsetAsync(c->A, 0, c->mp * c->ld * sizeof(float), c->stream));
   HIP_TRY(hipMemcpy2DAsync(c->A, c->ld * sizeof(float), A, ld_host * sizeof(float), n * sizeof(float), m, hipMemcpyHostToDevice, c->stream));
@@ -489,6 +676,12 @@ extern "C" int fh_set_matrix_f32(fh_ctx* c, const float* A, uint64_t m, uint64_t
 
 extern "C" int fh_generate_matrix(fh_ctx* c, uint64_t m, uint64_t n, uint64_t row0, uint64_t seed, double coef) {
   if (!c) return fail(FH_E_ARG, "null context");
+  if (!c->shards.empty()) {          // shell: every shard generates its own rows of the same counter-based matrix
+    FH_TRY(shell_partition(c, m, n));
+    for (int k = 0; k < nshards(c); ++k) FH_TRY(fh_generate_matrix(c->shards[k], shard_rows(c, k), n, row0 + c->shard_row0[k], seed, coef));
+    shell_adopt(c);
+    return 0;
+  }
   FH_TRY(setup_dense(c, m, n));
   const uint64_t key = fh_mix(seed);
   if (c->f32) k_gen_matrix<1><<<dim3(8192), dim3(FH_WG), 0, c->stream>>>(c->A, (uint32_t)(c->ld / 4), (uint32_t)m, (uint32_t)c->mp, (uint32_t)n, row0, key, coef);
@@ -502,6 +695,13 @@ extern "C" int fh_get_matrix_rows(fh_ctx* c, uint64_t row0, uint64_t nrows, doub
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "no dense matrix set");
   if (row0 + nrows > c->m) return fail(FH_E_ARG, "rows [%llu,%llu) out of range (m=%llu)", (unsigned long long)row0,
                                        (unsigned long long)(row0 + nrows), (unsigned long long)c->m);
+  if (!c->shards.empty()) {          // shell: gather from the shards that hold the rows
+    for (int k = 0; k < nshards(c); ++k) {
+      const uint64_t lo = std::max(row0, c->shard_row0[k]), hi = std::min(row0 + nrows, c->shard_row0[k + 1]);
+      if (lo < hi) FH_TRY(fh_get_matrix_rows(c->shards[k], lo - c->shard_row0[k], hi - lo, out + (lo - row0) * c->n));
+    }
+    return 0;
+  }
   FH_TRY(use_device(c));
   if (!c->f32) {
     HIP_TRY(hipMemcpy2DAsync(out, c->n * sizeof(double), c->A + row0 * c->ld, c->ld * sizeof(double), c->n * sizeof(double),
@@ -527,6 +727,7 @@ extern "C" int fh_set_stencil(fh_ctx* c, uint64_t H, uint64_t W) {
   if (!c) return fail(FH_E_ARG, "null context");
   if (H < 1 || W < 1) return fail(FH_E_ARG, "stencil needs H>=1 and W>=1 (got %llu x %llu)", (unsigned long long)H, (unsigned long long)W);
   if (H * W >= (1ull << 31)) return fail(FH_E_ARG, "image too large");
+  if (!c->shards.empty() || c->owner) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
   FH_TRY(use_device(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
   free_operator(c);
@@ -553,6 +754,11 @@ static int set_loss(fh_ctx* c, int kind, const double* b, uint64_t len) {
   if (c->op == OP_NONE) return fail(FH_E_STATE, "set the operator before the loss");
   if (len != c->m) return fail(FH_E_ARG, "b has %llu entries, operator has %llu rows", (unsigned long long)len, (unsigned long long)c->m);
   if (kind != LOSS_LSQ && c->op != OP_DENSE) return fail(FH_E_STATE, "the logistic loss is implemented for the dense operator");
+  if (!c->shards.empty()) {          // shell: b is sharded like the rows
+    for (int k = 0; k < nshards(c); ++k) FH_TRY(set_loss(c->shards[k], kind, b + c->shard_row0[k], shard_rows(c, k)));
+    c->has_b = true; c->loss_kind = kind;
+    return 0;
+  }
   FH_TRY(use_device(c));
   HIP_TRY(hipMemcpyAsync(c->b, b, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
   c->has_b = true;
@@ -572,6 +778,7 @@ extern "C" int fh_set_prox(fh_ctx* c, int kind, double mu, double lo, double hi)
   if (!c) return fail(FH_E_ARG, "null context");
   if (kind < FH_PROX_IDENTITY || kind > FH_PROX_BOX) return fail(FH_E_ARG, "unknown prox kind %d", kind);
   if (kind == FH_PROX_BOX && !(lo <= hi)) return fail(FH_E_ARG, "box prox needs lo <= hi");
+  for (fh_ctx* s : c->shards) { s->prox_kind = kind; s->mu = mu; s->lo = lo; s->hi = hi; }      // the prox is replicated work
   c->prox_kind = kind; c->mu = mu; c->lo = lo; c->hi = hi;
   return 0;
 }
@@ -638,9 +845,19 @@ static int lazy_vec(fh_ctx* c, int which, double** out) {
   return 0;
 }
 
+static inline bool m_side(int which) { return which == FH_VEC_B || which == FH_VEC_Z; }
+
 extern "C" int fh_set_vector(fh_ctx* c, int which, const double* host, uint64_t len) {
   if (!c || !host) return fail(FH_E_ARG, "null argument");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  if (!c->shards.empty()) {          // shell: n-side vectors are replicated, m-side vectors sharded like the rows
+    const uint64_t want = m_side(which) ? c->m : c->n;
+    if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
+    for (int k = 0; k < nshards(c); ++k)
+      FH_TRY(m_side(which) ? fh_set_vector(c->shards[k], which, host + c->shard_row0[k], shard_rows(c, k)) : fh_set_vector(c->shards[k], which, host, len));
+    if (which == FH_VEC_B) c->has_b = true;
+    return 0;
+  }
   if (which == FH_VEC_X0) c->lazy = false;          // a new start: fh_init follows
   uint64_t want = 0;
   double* d = vec_ptr(c, which, &want);
@@ -655,6 +872,13 @@ extern "C" int fh_set_vector(fh_ctx* c, int which, const double* host, uint64_t 
 extern "C" int fh_get_vector(fh_ctx* c, int which, double* host, uint64_t len) {
   if (!c || !host) return fail(FH_E_ARG, "null argument");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set");
+  if (!c->shards.empty()) {          // shell: replicated vectors from shard 0, sharded ones gathered
+    const uint64_t want = m_side(which) ? c->m : c->n;
+    if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
+    if (!m_side(which)) return fh_get_vector(c->shards[0], which, host, len);
+    for (int k = 0; k < nshards(c); ++k) FH_TRY(fh_get_vector(c->shards[k], which, host + c->shard_row0[k], shard_rows(c, k)));
+    return 0;
+  }
   uint64_t want = 0;
   double* d = vec_ptr(c, which, &want);
   FH_TRY(use_device(c));
@@ -814,18 +1038,6 @@ static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, c
   return 0;
 }
 
-// sharded adjoint tail: sum g1 (+ the local ||r||^2) over ranks, then the n-side epilogue
-static int allreduce_and_epilogue(fh_ctx* c, const AdjIO& io) {
-  t_begin(c, FH_K_COMM);
-  NCCL_TRY(g_rccl.GroupStart());
-  NCCL_TRY(g_rccl.AllReduce(io.g1, io.g1, (size_t)c->nv, kNcclFloat64, kNcclSum, c->comm, c->stream));
-  NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ_ADJ, c->dscal + FH_S_FSQ_ADJ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-  NCCL_TRY(g_rccl.GroupEnd());
-  t_end(c, FH_K_COMM);
-  if (io.mode != 0) return 0;
-  return bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ);
-}
-
 // sum|x_i| and max|x_i| of an n-length device vector -> dscal[GSUM], dscal[GMAX]  (g(x0) for objective_hist[0], :143)
 static int launch_gterms(fh_ctx* c, const double* x) {
   const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 1024);
@@ -879,7 +1091,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
     if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fwd_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
+    if (c->tv_nt == 1) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
     else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
 #undef TV_STEP
     t_end(c, FH_K_FWD);
@@ -895,7 +1107,7 @@ static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, cons
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   t_begin(c, FH_K_FWD);
-  if (c->tv_nt) k_fwd_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_nt == 1) k_fwd_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_fwd_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FWD);
   HIP_TRY(hipGetLastError());
@@ -919,7 +1131,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
     p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
     t_begin(c, FH_K_ADJ);
 #define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-    if (c->tv_nt) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
+    if (c->tv_nt == 1) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
     else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
 #undef TV_STEP
     t_end(c, FH_K_ADJ);
@@ -934,7 +1146,7 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
   FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
   t_begin(c, FH_K_ADJ);
-  if (c->tv_nt) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  if (c->tv_nt == 1) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_adj_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_ADJ);
   HIP_TRY(hipGetLastError());
@@ -1196,7 +1408,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
 // z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, fused_pays()):
 // identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
 static bool cu_masked() { return getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"); }
-static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !c->comm && fused_ppt(c) && fused_pays(c) && !cu_masked(); }
+static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !row_sharded(c) && c->shards.empty() && fused_ppt(c) && fused_pays(c) && !cu_masked(); }
 // returns 0 and sets *ok = false when the launch reported a spin timeout (caller falls back to two launches)
 static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bool* ok) {
   const FusedIO fio = {x, x, c->xhat, c->P[c->pc ^ 1], z, g, FH_PROX_IDENTITY, 2};
@@ -1215,31 +1427,63 @@ static int op_fwd(fh_ctx* c, int mode, double tau, const double* x0, const doubl
   return fail(FH_E_STATE, "no operator set");
 }
 
-static int op_adj(fh_ctx* c, const AdjIO& io_in) {
+// ---- the adjoint launch in three stages, so that a shell can run stage 1 on every shard, ONE exchange, stage 3 on every shard ----
+// stage 1, local: row-sharded contexts leave the n-side epilogue (mode 0) to adj_tail, which needs the summed g1
+static int adj_local(fh_ctx* c, const AdjIO& io_in) {
   AdjIO io = io_in;
-  const bool sharded = c->comm != nullptr;
-  if (sharded && c->op != OP_DENSE) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
-  if (sharded && io.mode == 0) io.mode = 2;
-  if (c->op == OP_DENSE) FH_TRY(launch_adj_dense(c, io));
-  else if (c->op == OP_STENCIL) FH_TRY(launch_adj_tv(c, io));
-  else return fail(FH_E_STATE, "no operator set");
-  if (sharded) { io.mode = io_in.mode; FH_TRY(allreduce_and_epilogue(c, io)); }
-  return 0;
+  if (row_sharded(c) && c->op != OP_DENSE) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+  if (row_sharded(c) && io.mode == 0) io.mode = 2;
+  if (c->op == OP_DENSE) return launch_adj_dense(c, io);
+  if (c->op == OP_STENCIL) return launch_adj_tv(c, io);
+  return fail(FH_E_STATE, "no operator set");
+}
+// stage 2, exchange: A_k^T r_k partials (nv doubles at g1(shard)) and the local loss sums (FH_S_FSQ_ADJ) summed over the row blocks
+template <typename Sel>
+static int adj_sum(fh_ctx* c, Sel g1) {
+  return sum_over_shards(c, g1, (size_t)c->nv, [](fh_ctx* s) { return s->dscal + FH_S_FSQ_ADJ; }, 1);
+}
+// stage 3: the n-side epilogue on the summed g1
+static int adj_tail(fh_ctx* c, const AdjIO& io) {
+  if (!row_sharded(c) || io.mode != 0) return 0;
+  return bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ);
+}
+// all three on a plain context (fh_init, fh_gradient_at, fh_apply of a single context)
+static int op_adj(fh_ctx* c, const AdjIO& io) {
+  FH_TRY(adj_local(c, io));
+  double* g1 = io.g1;
+  FH_TRY(adj_sum(c, [g1](fh_ctx*) { return g1; }));
+  return adj_tail(c, io);
 }
 
+// local ||r_k||^2 (or logistic loss sum) of the forward launch summed over the row blocks, before the host's line-search test
 static int reduce_fsq_over_ranks(fh_ctx* c) {
-  if (!c->comm) return 0;
-  t_begin(c, FH_K_COMM);
-  NCCL_TRY(g_rccl.AllReduce(c->dscal + FH_S_FSQ, c->dscal + FH_S_FSQ, 1, kNcclFloat64, kNcclSum, c->comm, c->stream));
-  t_end(c, FH_K_COMM);
-  return 0;
+  return sum_over_shards(c, [](fh_ctx* s) { return s->dscal + FH_S_FSQ; }, 1);
 }
 
 static int check_ready(fh_ctx* c, bool need_b) {
   if (!c) return fail(FH_E_ARG, "null context");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set (call fh_set_matrix / fh_generate_matrix / fh_set_stencil)");
   if (need_b && !c->has_b) return fail(FH_E_STATE, "no loss set (call fh_set_loss_lsq)");
-  return use_device(c);
+  return c->shards.empty() ? use_device(c) : 0;      // (a shell selects the device shard by shard)
+}
+
+// the solver-state operands of K-adj / the n-side epilogue (fh_adj, fh_fwd_adj, fh_step on a row-sharded context)
+static AdjIO solver_adj_io(fh_ctx* c, double tau, int accel, double coef) {
+  AdjIO io;
+  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
+  io.mode = 0; io.tau = tau;
+  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
+  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
+  return io;
+}
+// K-fwd of the solver state (level search for the two sort-free prox kinds first)
+static int solver_fwd_local(fh_ctx* c, double tau, const char* who) {
+  FH_TRY(use_device(c));
+  FH_TRY(not_lazy(c, who));
+  FH_TRY(tv_refresh_zcur(c));
+  c->tvz_pending = false;
+  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
+  return op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1247,50 +1491,71 @@ static int check_ready(fh_ctx* c, bool need_b) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_init(fh_ctx* c, double* scalars) {
   FH_TRY(check_ready(c, true));
-  c->lazy = false; c->commits = 0; c->tvz_pending = false; c->zcur_stale = false;
-  double* x0 = c->X[c->xi];
+  const int ns = nshards(c);
   // z_accel1 := A x0 lands in Z[zc] so the first iteration finds it as z_accel0 (fasta/__init__.py:154-157)
   bool fused_done = false;
-  if (plain_pair_fused_ok(c)) FH_TRY(plain_pair_fused(c, x0, c->Z[c->zc], c->G[c->gc], &fused_done));   // one pass: z, f, gradient
+  for (int k = 0; k < ns; ++k) { fh_ctx* s = shard_of(c, k); s->lazy = false; s->commits = 0; s->tvz_pending = false; s->zcur_stale = false; }
+  if (plain_pair_fused_ok(c)) FH_TRY(plain_pair_fused(c, c->X[c->xi], c->Z[c->zc], c->G[c->gc], &fused_done));   // one pass: z, f, gradient
   if (!fused_done) {
-  FH_TRY(op_fwd(c, 1, 0.0, x0, nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 1));
-  FH_TRY(reduce_fsq_over_ranks(c));
-  if (c->op == OP_STENCIL) {
-    c->zcur = c->Z[c->zc];       // g0 = grad(zcur - b) is recomputed inside the step kernels
-  } else {
-    AdjIO io = {c->Z[c->zc], nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->G[c->gc]};
-    FH_TRY(op_adj(c, io));
+    for (int k = 0; k < ns; ++k) {
+      fh_ctx* s = shard_of(c, k);
+      FH_TRY(use_device(s));
+      FH_TRY(op_fwd(s, 1, 0.0, s->X[s->xi], nullptr, nullptr, nullptr, nullptr, s->Z[s->zc], 1));
+    }
+    FH_TRY(reduce_fsq_over_ranks(c));
+    for (int k = 0; k < ns; ++k) {
+      fh_ctx* s = shard_of(c, k);
+      if (s->op == OP_STENCIL) { s->zcur = s->Z[s->zc]; continue; }     // g0 = grad(zcur - b) is recomputed inside the step kernels
+      FH_TRY(use_device(s));
+      AdjIO io = {s->Z[s->zc], nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, s->G[s->gc]};
+      FH_TRY(adj_local(s, io));
+    }
+    if (shard_of(c, 0)->op == OP_DENSE) FH_TRY(adj_sum(c, [](fh_ctx* s) { return s->G[s->gc]; }));
   }
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    FH_TRY(use_device(s));
+    double* x0 = s->X[s->xi];
+    // x_accel1 := x0, best := x0 ; g(x0) terms for objective_hist[0] (:143) come from the host wrapper via FH_VEC ops
+    HIP_TRY(hipMemcpyAsync(s->P[s->pc], x0, s->nv * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    s->bi = s->xi;                         // best iterate := x0 (fasta/__init__.py:167), by reference
+    for (int q = 0; q < 3; ++q) if (q != s->xi) { s->ti = q; break; }
+    s->last_accel = false;
+    FH_TRY(launch_gterms(s, x0));
   }
-  // x_accel1 := x0, best := x0 ; g(x0) terms for objective_hist[0] (:143) come from the host wrapper via FH_VEC ops
-  HIP_TRY(hipMemcpyAsync(c->P[c->pc], x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  c->bi = c->xi;                         // best iterate := x0 (fasta/__init__.py:167), by reference
-  for (int k = 0; k < 3; ++k) if (k != c->xi) { c->ti = k; break; }
-  c->last_accel = false;
-  FH_TRY(launch_gterms(c, x0));
   return fetch_scalars(c, scalars);
 }
 
 extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec) {
   FH_TRY(check_ready(c, true));
-  uint64_t l1 = 0, l2 = 0;
-  double* src = vec_ptr(c, src_vec, &l1);
-  double* dst = vec_ptr(c, dst_vec, &l2);
-  if (!src || !dst || l1 != c->n || l2 != c->n) return fail(FH_E_ARG, "fh_gradient_at needs two n-length vectors");
-  if (plain_pair_fused_ok(c)) {
-    bool ok = false;
-    FH_TRY(plain_pair_fused(c, src, c->zt, dst, &ok));
-    if (ok) return 0;
+  const int ns = nshards(c);
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    uint64_t l1 = 0, l2 = 0;
+    double* src = vec_ptr(s, src_vec, &l1);
+    double* dst = vec_ptr(s, dst_vec, &l2);
+    if (!src || !dst || l1 != s->n || l2 != s->n) return fail(FH_E_ARG, "fh_gradient_at needs two n-length vectors");
+    if (plain_pair_fused_ok(s)) {
+      bool ok = false;
+      FH_TRY(plain_pair_fused(s, src, s->zt, dst, &ok));
+      if (ok) return 0;
+    }
+    FH_TRY(use_device(s));
+    FH_TRY(op_fwd(s, 1, 0.0, src, nullptr, nullptr, nullptr, nullptr, s->zt, 1));
+    AdjIO io = {s->zt, nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, dst};
+    FH_TRY(adj_local(s, io));
   }
-  FH_TRY(op_fwd(c, 1, 0.0, src, nullptr, nullptr, nullptr, nullptr, c->zt, 1));
-  AdjIO io = {c->zt, nullptr, 1, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, dst};
-  FH_TRY(op_adj(c, io));
+  FH_TRY(adj_sum(c, [dst_vec](fh_ctx* s) { uint64_t l = 0; return vec_ptr(s, dst_vec, &l); }));
   return finish(c);
 }
 
 extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
   FH_TRY(check_ready(c, false));
   if (!out) return fail(FH_E_ARG, "null out");
+  if (!c->shards.empty()) {                        // n-side vectors are replicated: any shard has the answer
+    if (m_side(vec_a) || m_side(vec_b)) return fail(FH_E_ARG, "fh_diff_norm on a multi-device context takes n-side vectors");
+    return fh_diff_norm(c->shards[0], vec_a, vec_b, out);
+  }
   uint64_t l1 = 0, l2 = 0;
   double* a = vec_ptr(c, vec_a, &l1);
   double* b = vec_ptr(c, vec_b, &l2);
@@ -1307,25 +1572,34 @@ extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
 
 extern "C" int fh_fwd(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
-  FH_TRY(not_lazy(c, "fh_fwd"));
-  FH_TRY(tv_refresh_zcur(c));
-  c->tvz_pending = false;
-  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
+  for (int k = 0; k < nshards(c); ++k) FH_TRY(solver_fwd_local(shard_of(c, k), tau, "fh_fwd"));
   FH_TRY(reduce_fsq_over_ranks(c));
   return fetch_scalars(c, scalars);
 }
 
+// K-adj of the solver state on every row block, one exchange, the n-side epilogue on every row block
+static int solver_adj(fh_ctx* c, double tau, int accel, double coef, const char* who) {
+  const int ns = nshards(c);
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    FH_TRY(use_device(s));
+    FH_TRY(not_lazy(s, who));
+    s->last_accel = accel != 0;
+    FH_TRY(adj_local(s, solver_adj_io(s, tau, accel, coef)));
+  }
+  FH_TRY(adj_sum(c, [](fh_ctx* s) { return s->G[s->gc ^ 1]; }));
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    if (!row_sharded(s)) continue;
+    FH_TRY(use_device(s));
+    FH_TRY(adj_tail(s, solver_adj_io(s, tau, accel, coef)));
+  }
+  return 0;
+}
+
 extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* scalars) {
   FH_TRY(check_ready(c, true));
-  FH_TRY(not_lazy(c, "fh_adj"));
-  AdjIO io;
-  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
-  io.mode = 0; io.tau = tau;
-  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
-  c->last_accel = accel != 0;
-  FH_TRY(op_adj(c, io));
+  FH_TRY(solver_adj(c, tau, accel, coef, "fh_adj"));
   return fetch_scalars(c, scalars);
 }
 
@@ -1334,24 +1608,24 @@ extern "C" int fh_adj(fh_ctx* c, double tau, int accel, double coef, double* sca
 // (fasta/__init__.py:181-188 and :248-260 in one call; a rejected step has wasted the K-adj launch).
 extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
-  FH_TRY(not_lazy(c, "fh_fwd_adj"));
-  FH_TRY(tv_refresh_zcur(c));
-  c->tvz_pending = false;
-  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  FH_TRY(op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1));
+  for (int k = 0; k < nshards(c); ++k) FH_TRY(solver_fwd_local(shard_of(c, k), tau, "fh_fwd_adj"));
   FH_TRY(reduce_fsq_over_ranks(c));
-  AdjIO io;
-  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = 0; io.coef = 0.0;
-  io.mode = 0; io.tau = tau;
-  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
-  c->last_accel = false;
-  FH_TRY(op_adj(c, io));
+  FH_TRY(solver_adj(c, tau, 0, 0.0, "fh_fwd_adj"));
   return fetch_scalars(c, scalars);
 }
 
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
+  if (!c->shards.empty()) {          // shell: what every shard supports (row blocks may differ by one row; the kinds rarely differ)
+    int all = -1;
+    for (fh_ctx* s : c->shards) {
+      int one = 0;
+      FH_TRY(fh_fused_supported(s, &one));
+      all = all < 0 ? one : (all == one ? all : ((all && one) ? 3 : 0));
+    }
+    *yes = all;
+    return 0;
+  }
   // 0 = unsupported; 1 = dense one-pass kernel, recommended;
   // 2 = stencil one-pass kernel (costs no more than K-fwd alone: it simply replaces both launches);
   // 3 = dense one-pass kernel available but NOT recommended: its launch has ~35-50 us of fixed cost (slot fill, n-side
@@ -1362,7 +1636,7 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // CUs from the dispatcher without changing that count: say "unsupported" up front instead of running into the bounded-spin
   // timeout on the first launch (the timeout stays as the safety net for partition modes this check cannot see).
   if (ppt && (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))) ppt = 0;
-  *yes = c->op == OP_STENCIL ? (c->comm ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
+  *yes = c->op == OP_STENCIL ? (row_sharded(c) ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
   return 0;
 }
 
@@ -1385,7 +1659,7 @@ static int launch_fused_tv(fh_ctx* c, double tau) {
     if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fused_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-  if (c->tv_nt) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 4) TV_FUSED(4, 1); else TV_FUSED(8, 1); }
+  if (c->tv_nt == 1) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 4) TV_FUSED(4, 1); else TV_FUSED(8, 1); }
   else { if (c->tv_u == 2) TV_FUSED(2, 0); else if (c->tv_u == 4) TV_FUSED(4, 0); else TV_FUSED(8, 0); }
 #undef TV_FUSED
   t_end(c, FH_K_FUSED);
@@ -1412,7 +1686,7 @@ static int launch_fused_tv_accel(fh_ctx* c, double tau, double coef, int restart
     if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_accel<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
     else k_fused_tv_accel<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
   } while (0)
-  if (c->tv_nt) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 4) TV_ACCEL(4, 1); else TV_ACCEL(8, 1); }
+  if (c->tv_nt == 1) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 4) TV_ACCEL(4, 1); else TV_ACCEL(8, 1); }
   else { if (c->tv_u == 2) TV_ACCEL(2, 0); else if (c->tv_u == 4) TV_ACCEL(4, 0); else TV_ACCEL(8, 0); }
 #undef TV_ACCEL
   t_end(c, FH_K_FUSED);
@@ -1426,9 +1700,20 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
     return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
   TvZP p;
   p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 128);         // rows+4 rows are read per chunk: 128 keeps that at 3 %
-  const int tvu = c->tv_u ? c->tv_u : (accel ? 4 : 2);
   p.strip_groups = ((p.W + TVZ_OWN - 1) / TVZ_OWN + 3) / 4;
+  if (c->tv_rows > 0) p.rows_wg = (uint32_t)c->tv_rows;
+  else {
+    // auto: as many row chunks as make the grid just FILL the resident capacity (5 workgroups per CU at 88 registers), so that all
+    // workgroups run side by side and finish together -- 2240 workgroups of 128 rows on 1280 slots ran 1.75 rounds, the last one
+    // three-quarters empty (8192^2: 128 rows 0.607 ms, 228-235 rows 0.588; profiles/r02_tune_tv.txt, r03_tune_tv.txt).  At least
+    // 32 rows per chunk (rows + 4 are read and computed), at most the image.
+    const uint32_t slots = (uint32_t)std::max(1, c->ncu) * 5u;
+    const uint32_t chunks = std::max(1u, slots / p.strip_groups);
+    p.rows_wg = std::min(p.H, std::max(32u, (p.H + chunks - 1) / chunks));
+  }
+  // rows per trip / rotating trip buffers: 2 rows, load-then-consume for the plain sweep; 4 rows x 3 rotating buffers with FISTA
+  // (two streams to read): profiles/r03_tune_tv.txt.  Every combination produces the same bits (scripts/tune_tvz.py).
+  const int tvu = c->tv_u ? c->tv_u : (accel ? 4 : 2);
   if (accel) { p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn); p.cprev = c->lc; }
   else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }
   p.b = c->b; p.tau = tau; p.coef = coef; p.restart = restart;
@@ -1436,12 +1721,21 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
-#define TVZ(ID, AC, U, NT) k_tv_onepass<ID, AC, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-#define TVZ_U(ID, AC, NT) do { if (tvu == 2) TVZ(ID, AC, 2, NT); else if (tvu == 8) TVZ(ID, AC, 8, NT); else TVZ(ID, AC, 4, NT); } while (0)
-#define TVZ_NT(ID, AC) do { if (c->tv_nt) TVZ_U(ID, AC, 1); else TVZ_U(ID, AC, 0); } while (0)
+  // tunables -> template parameters.  Non-temporal LOADS lose 12 % here (the halo columns and rows are re-read by the neighbouring
+  // waves and workgroups through L2), so this sweep only distinguishes non-temporal (default) and plain STORES (FH_TUNE_TV_NT = 3).
+  const int nb = c->tv_pipe ? c->tv_pipe : (accel ? 3 : 1);
+  const bool nts = c->tv_nt != 3;       // stores are non-temporal unless FH_TUNE_TV_NT = 3 asks for plain ones (+2-3 %: xprox is not re-read by this launch)
   const bool ident = c->prox_kind != FH_PROX_TVBALL;
-  if (accel) { if (ident) TVZ_NT(1, 1); else TVZ_NT(0, 1); }
-  else { if (ident) TVZ_NT(1, 0); else TVZ_NT(0, 0); }
+#define TVZ(ID, AC, U, NT, NB) k_tv_onepass<ID, AC, U, NT, NB><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
+#define TVZ_NB(AC, U, NT) do { if (nb >= 2) TVZ(0, AC, U, NT, 3); else TVZ(0, AC, U, NT, 1); } while (0)
+#define TVZ_U(AC, NT) do { if (tvu <= 2) TVZ_NB(AC, 2, NT); else if (tvu == 8) TVZ_NB(AC, 8, NT); else TVZ_NB(AC, 4, NT); } while (0)
+#define TVZ_NT(AC) do { if (nts) TVZ_U(AC, 2); else TVZ_U(AC, 0); } while (0)
+  if (ident) {        // no prox (g = None): the round-2 burst form
+    if (accel) { if (tvu == 2) TVZ(1, 1, 2, 0, 1); else if (tvu == 8) TVZ(1, 1, 8, 0, 1); else TVZ(1, 1, 4, 0, 1); }
+    else { if (tvu == 2) TVZ(1, 0, 2, 0, 1); else if (tvu == 8) TVZ(1, 0, 8, 0, 1); else TVZ(1, 0, 4, 0, 1); }
+  } else if (accel) TVZ_NT(1);
+  else TVZ_NT(0);
+#undef TVZ_NB
 #undef TVZ_NT
 #undef TVZ_U
 #undef TVZ
@@ -1451,13 +1745,50 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   return 0;
 }
 
+// One-pass iteration of the dense operator on every row block (`accel` = 0: fh_step; 1: fh_step_accel): local launch on every
+// shard -> ONE sum over the row blocks of g1 with the local loss sums and the timeout word appended (every shard / rank then sees
+// the same verdict, so all of them drop to the two-launch path together if a hand-off ever times out) -> the n-side epilogue on
+// every shard -> one host synchronisation.  A plain single-GPU context is the one-shard case without the exchange.
+static int dense_step(fh_ctx* c, double tau, int accel, double coef, int restart, double* scalars) {
+  const int ns = nshards(c);
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    FH_TRY(use_device(s));
+    if (s->prox_kind == FH_PROX_LINF || s->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(s, tau));
+    const bool sharded = row_sharded(s);
+    double* g1 = s->G[s->gc ^ 1];
+    FusedIO fio = {s->X[s->xi], s->G[s->gc], s->xhat, s->P[s->pc ^ 1], s->Z[s->zc ^ 1], g1, s->prox_kind, sharded ? 2 : 0};
+    if (accel) {
+      fio.accel = 1; fio.restart = restart ? 1 : 0; fio.coef = coef;
+      fio.xacc0 = s->P[s->pc]; fio.zacc0 = s->Z[s->zc]; fio.x1 = s->X[s->ti];
+      fio.coef_out = sharded ? s->dscal + FH_NSCALARS + 3 : nullptr;     // the applied coefficient, for the separate epilogue
+    }
+    if (sharded) fio.pack = g1 + s->nv;          // slack behind every n-side vector (alloc_vectors)
+    FH_TRY(launch_fused_dense(s, tau, fio));
+    s->last_accel = accel != 0;
+  }
+  FH_TRY(sum_over_shards(c, [](fh_ctx* s) { return s->G[s->gc ^ 1]; }, (size_t)shard_of(c, 0)->nv + 3));
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    if (!row_sharded(s)) continue;
+    FH_TRY(use_device(s));
+    AdjIO io = solver_adj_io(s, tau, accel, coef);
+    io.z = nullptr; io.zacc0 = nullptr;
+    double* pack = io.g1 + s->nv;
+    FH_TRY(bb_epilogue_only(s, io, accel ? pack + 2 : pack, accel ? s->dscal + FH_NSCALARS + 3 : nullptr, pack));
+  }
+  FH_TRY(fetch_scalars(c, scalars));
+  for (int k = 0; k < ns; ++k) fused_after(shard_of(c, k));
+  return 0;
+}
+
 // One-pass FBS iteration: K-fwd and K-adj of the same tau from a single read of A (no acceleration).
 // Writes the complete FH_S_* block; scalars[15] != 0 reports a spin timeout (results invalid: use the two-launch path).
 extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
   FH_TRY(check_ready(c, true));
-  FH_TRY(not_lazy(c, "fh_step"));
+  for (int k = 0; k < nshards(c); ++k) FH_TRY(not_lazy(shard_of(c, k), "fh_step"));
   if (c->op == OP_STENCIL) {
-    if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+    if (row_sharded(c)) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
     if (c->tv_zfree) {
       if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
       FH_TRY(launch_tv_onepass(c, tau, 0, 0.0, 0));
@@ -1469,29 +1800,7 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
     c->last_accel = false;
     return fetch_scalars(c, scalars);
   }
-  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  const bool sharded = c->comm != nullptr;
-  double* g1 = c->G[c->gc ^ 1];
-  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], g1, c->prox_kind, sharded ? 2 : 0};
-  double* pack = g1 + c->nv;                   // slack behind every n-side vector (alloc_vectors)
-  if (sharded) fio.pack = pack;
-  FH_TRY(launch_fused_dense(c, tau, fio));
-  c->last_accel = false;
-  if (sharded) {
-    // ONE collective per iteration: g1 with the local loss sum and the timeout word appended (every rank then sees the same
-    // verdict, so all of them drop to the two-launch path together if a hand-off ever times out)
-    t_begin(c, FH_K_COMM);
-    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv + 3, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    t_end(c, FH_K_COMM);
-    AdjIO io;
-    io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 0; io.coef = 0.0; io.mode = 0; io.tau = tau;
-    io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-    io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
-    FH_TRY(bb_epilogue_only(c, io, pack, nullptr, pack));
-  }
-  FH_TRY(fetch_scalars(c, scalars));
-  fused_after(c);
-  return 0;
+  return dense_step(c, tau, 0, 0.0, 0, scalars);
 }
 
 // One-pass iteration WITH acceleration (fasta/__init__.py:220-248): the launch computes this step's restart dot before
@@ -1502,7 +1811,7 @@ extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
 extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, double* scalars) {
   FH_TRY(check_ready(c, true));
   if (c->op == OP_STENCIL) {
-    if (c->comm) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
+    if (row_sharded(c)) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
     if (!c->lazy) {      // first accelerated one-pass step after fh_init: x0 = X[xi] (c = 0), z(x0) = Z[zc], best = x0
       if (!c->zcur) return fail(FH_E_STATE, "fh_step_accel on the stencil operator before fh_init");
       if (c->commits) return fail(FH_E_STATE, "fh_step_accel on the stencil operator must drive the solve from the first iteration after fh_init");
@@ -1519,35 +1828,15 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
     c->lc_pending = (restart && c->hscal[FH_S_RDOT] > 1E-30) ? 0.0 : coef;      // what the launch applied (:231); adopted by fh_commit
     return 0;
   }
-  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  const bool sharded = c->comm != nullptr;
-  double* g1 = c->G[c->gc ^ 1];
-  double* coef_dev = c->dscal + FH_NSCALARS + 3;
-  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], g1, c->prox_kind, sharded ? 2 : 0};
-  fio.accel = 1; fio.restart = restart ? 1 : 0; fio.coef = coef;
-  fio.xacc0 = c->P[c->pc]; fio.zacc0 = c->Z[c->zc]; fio.x1 = c->X[c->ti];
-  fio.coef_out = sharded ? coef_dev : nullptr;
-  double* pack = g1 + c->nv;
-  if (sharded) fio.pack = pack;
-  FH_TRY(launch_fused_dense(c, tau, fio));
-  c->last_accel = true;
-  if (sharded) {
-    t_begin(c, FH_K_COMM);
-    NCCL_TRY(g_rccl.AllReduce(g1, g1, (size_t)c->nv + 3, kNcclFloat64, kNcclSum, c->comm, c->stream));   // g1 + loss sums + timeout word
-    t_end(c, FH_K_COMM);
-    AdjIO io;
-    io.z = nullptr; io.zacc0 = nullptr; io.sub_b = 1; io.accel = 1; io.coef = coef; io.mode = 0; io.tau = tau;
-    io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-    io.x1 = c->X[c->ti]; io.g1 = g1; io.g0 = c->G[c->gc];
-    FH_TRY(bb_epilogue_only(c, io, pack + 2, coef_dev, pack));
-  }
-  FH_TRY(fetch_scalars(c, scalars));
-  fused_after(c);
-  return 0;
+  return dense_step(c, tau, 1, coef, restart, scalars);
 }
 
 extern "C" int fh_commit(fh_ctx* c, int save_best) {
   FH_TRY(check_ready(c, false));
+  if (!c->shards.empty()) {          // shell: the same rotation on every shard (pointer bookkeeping only)
+    for (fh_ctx* s : c->shards) FH_TRY(fh_commit(s, save_best));
+    return 0;
+  }
   c->commits += 1;
   if (c->op == OP_STENCIL && c->tvz_pending && !c->lazy) c->zcur_stale = true;     // the adopted x0 has no stored image
   c->tvz_pending = false;
@@ -1581,15 +1870,27 @@ extern "C" int fh_commit(fh_ctx* c, int save_best) {
 extern "C" int fh_apply(fh_ctx* c, int adjoint, const double* in, double* out) {
   FH_TRY(check_ready(c, false));
   if (!in || !out) return fail(FH_E_ARG, "null argument");
-  if (!adjoint) {
-    HIP_TRY(hipMemcpyAsync(c->T[3], in, c->n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    FH_TRY(op_fwd(c, 1, 0.0, c->T[3], nullptr, nullptr, nullptr, nullptr, c->zt, 0));
-    HIP_TRY(hipMemcpyAsync(out, c->zt, c->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  } else {
-    HIP_TRY(hipMemcpyAsync(c->zt, in, c->m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    AdjIO io = {c->zt, nullptr, 0, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, c->T[3]};
-    FH_TRY(op_adj(c, io));
-    HIP_TRY(hipMemcpyAsync(out, c->T[3], c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const int ns = nshards(c);
+  const bool shell = !c->shards.empty();
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    const uint64_t r0 = shell ? c->shard_row0[k] : 0;       // rows of the whole operator this shard holds: [r0, r0 + s->m)
+    FH_TRY(use_device(s));
+    if (!adjoint) {
+      HIP_TRY(hipMemcpyAsync(s->T[3], in, s->n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      FH_TRY(op_fwd(s, 1, 0.0, s->T[3], nullptr, nullptr, nullptr, nullptr, s->zt, 0));
+      HIP_TRY(hipMemcpyAsync(out + r0, s->zt, s->m * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(s->zt, in + r0, s->m * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      AdjIO io = {s->zt, nullptr, 0, 0, 0.0, 1, 1.0, nullptr, nullptr, nullptr, nullptr, nullptr, s->T[3]};
+      FH_TRY(adj_local(s, io));
+    }
+  }
+  if (adjoint) {
+    FH_TRY(adj_sum(c, [](fh_ctx* s) { return s->T[3]; }));
+    fh_ctx* s0 = shard_of(c, 0);
+    FH_TRY(use_device(s0));
+    HIP_TRY(hipMemcpyAsync(out, s0->T[3], s0->n * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
   }
   return finish(c);
 }
@@ -1609,6 +1910,8 @@ extern "C" int fh_comm_unique_id(void* id128) {
 extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) {
   if (!c || !id128) return fail(FH_E_ARG, "null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(FH_E_ARG, "bad rank %d of %d", rank, nranks);
+  if (!c->shards.empty() || c->owner)
+    return fail(FH_E_STATE, "fh_comm_init: a multi-device context (fh_create_ex, ndev > 1) already shards the rows in-process");
   FH_TRY(rccl_load());
   FH_TRY(use_device(c));
   if (c->comm) FH_TRY(fh_comm_destroy(c));
@@ -1622,12 +1925,17 @@ extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) 
 extern "C" int fh_comm_count(fh_ctx* c, int* nranks) {
   if (!c || !nranks) return fail(FH_E_ARG, "null argument");
   *nranks = 1;                       // no communicator: a single-GPU context
+  if (!c->shards.empty()) {          // shell: what RCCL reports for shard 0's communicator; shards on one device: their number
+    if (c->emulated) { *nranks = (int)c->shards.size(); return 0; }
+    c = c->shards[0];
+  }
   if (c->comm) NCCL_TRY(g_rccl.CommCount(c->comm, nranks));   // what RCCL itself reports, not what the caller asked for
   return 0;
 }
 
 extern "C" int fh_comm_destroy(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
+  if (!c->shards.empty() || c->owner) return fail(FH_E_STATE, "fh_comm_destroy: the communicators of a multi-device context live as long as it does (fh_destroy)");
   if (c->comm) {
     (void)hipStreamSynchronize(c->stream);
     NCCL_TRY(g_rccl.CommDestroy(c->comm));
@@ -1641,26 +1949,51 @@ extern "C" int fh_comm_destroy(fh_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int fh_timing_enable(fh_ctx* c, int on) {
   if (!c) return fail(FH_E_ARG, "null context");
+  for (fh_ctx* s : c->shards) s->timing = on != 0;
   c->timing = on != 0;
   return 0;
 }
+// a multi-device context reports the SUM over its shards of each kernel's time and launches (shards on one device run one after
+// the other; on separate devices the per-launch average total_ms / launches is the mean over the devices)
 extern "C" int fh_timing_get(fh_ctx* c, int k, double* total_ms, uint64_t* launches) {
   if (!c || k < 0 || k >= FH_NKERNELS) return fail(FH_E_ARG, "bad kernel id");
-  if (total_ms) *total_ms = c->tot_ms[k];
-  if (launches) *launches = c->launches[k];
+  double ms = c->tot_ms[k];
+  uint64_t cnt = c->launches[k];
+  for (fh_ctx* s : c->shards) { ms += s->tot_ms[k]; cnt += s->launches[k]; }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = cnt;
   return 0;
 }
 extern "C" int fh_timing_reset(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
+  for (fh_ctx* s : c->shards) FH_TRY(fh_timing_reset(s));
   for (int k = 0; k < FH_NKERNELS; ++k) { c->tot_ms[k] = 0; c->launches[k] = 0; c->ev_pending[k] = false; }
+  return 0;
+}
+
+// number of row blocks of a context (1 for a plain one) and borrowed access to one of them -- the shard is a complete context
+// (diagnostics and tests read its replicated vectors with fh_get_vector; it stays owned by the multi-device context)
+extern "C" int fh_shard_count(fh_ctx* c, int* count) {
+  if (!c || !count) return fail(FH_E_ARG, "null argument");
+  *count = nshards(c);
+  return 0;
+}
+extern "C" int fh_shard(fh_ctx* c, int k, fh_ctx** shard, uint64_t* row0, uint64_t* rows) {
+  if (!c || !shard) return fail(FH_E_ARG, "null argument");
+  if (k < 0 || k >= nshards(c)) return fail(FH_E_ARG, "shard %d out of range (have %d)", k, nshards(c));
+  *shard = shard_of(c, k);
+  const bool laid_out = !c->shards.empty() && c->shard_row0.size() == c->shards.size() + 1;
+  if (row0) *row0 = laid_out ? c->shard_row0[(size_t)k] : 0;
+  if (rows) *rows = laid_out ? shard_rows(c, k) : c->m;
   return 0;
 }
 
 extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint64_t* bytes_per_pass) {
   FH_TRY(check_ready(c, false));
+  if (!c->shards.empty()) return fh_stream_read_ms(c->shards[0], reps, ms_per_pass, bytes_per_pass);     // shard 0's block on its device
   if (c->op != OP_DENSE) return fail(FH_E_STATE, "stream-read ceiling needs a dense matrix");
   if (reps < 1) reps = 1;
-  // persistent workgroups, 1 per CU by default (FH_TUNE_FWD_GRID_CAP overrides), two register buffers of 16 nt loads per lane
+  // k_stream_probe<16,1> as described in include/fasta_hip.h: persistent workgroups, 1 per CU by default, three rotating buffers of 16 nt loads per lane
   const uint64_t npieces = c->mp * (c->ld / (c->f32 ? 4 : 2));
   const unsigned grid = (unsigned)(c->fwd_cap > 0 ? c->fwd_cap : (c->ncu > 0 ? c->ncu : 256));
   double* sink = c->dscal + FH_NSCALARS + 2;

@@ -34,6 +34,19 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
   return r;
 }
 
+// (base + off) mod H for the few rows a sweep steps outside its chunk (base < H, off in [-2, rows + 1], rows <= H - base): two
+// conditional corrections per side cover every H >= 1.  NOT a 64-bit `%`: hipcc expands that into ~140 scalar instructions, and
+// with two of them per image row the round-2 sweeps were bound by the CU's scalar unit (88 % busy), not by HBM.
+__device__ __forceinline__ uint32_t tv_wrap_row(uint32_t base, int off, uint32_t H) {
+  int r = (int)base + off;
+  const int h = (int)H;
+  if (r < 0) r += h;
+  if (r < 0) r += h;
+  if (r >= h) r -= h;
+  if (r >= h) r -= h;
+  return (uint32_t)r;
+}
+
 template <int NT>
 __device__ __forceinline__ void store_d2(d2* p, d2 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 template <int NT>
@@ -476,10 +489,7 @@ __global__ __launch_bounds__(FH_WG) void k_fused_tv_step(const TvStepFwdP p) {
   double u[5] = {0, 0, 0, 0, 0};                                  // dxdg, dg2, xh2(adj), gsum, gmax
   double fs = 0.0;
 
-  auto row_of = [&](uint32_t base, int off) -> uint32_t {        // (base + off) mod H, periodic
-    const int64_t Hh = (int64_t)p.H;
-    return (uint32_t)((((int64_t)base + off) % Hh + Hh) % Hh);
-  };
+  auto row_of = [&](uint32_t base, int off) -> uint32_t { return tv_wrap_row(base, off, p.H); };   // (base + off) mod H, periodic
   auto resid_at = [&](uint32_t row) -> double {
     const uint64_t pix = (uint64_t)row * p.W + cw;
     return sub_nofma(load_f64<NT>(p.zc + pix), load_f64<NT>(p.b + pix));
@@ -663,10 +673,7 @@ __global__ __launch_bounds__(FH_WG) void k_fused_tv_accel(const TvAccelP p) {
   double u1[6] = {0, 0, 0, 0, 0, 0};                              // candidate c = coef: dxdg, dg2, xh2, gsum, gmax, f
   double fs = 0.0;
 
-  auto row_of = [&](uint32_t base, int off) -> uint32_t {
-    const int64_t Hh = (int64_t)p.H;
-    return (uint32_t)((((int64_t)base + off) % Hh + Hh) % Hh);
-  };
+  auto row_of = [&](uint32_t base, int off) -> uint32_t { return tv_wrap_row(base, off, p.H); };
   auto x0_of = [&](d2 p1v, d2 p0v) -> d2 {                        // :242 of the previous iteration, evaluated now
     if (!lag) return p1v;
     d2 x;
@@ -899,8 +906,10 @@ struct TvZP {
   double* red; unsigned* counter; double* out;
 };
 
-template <int IDENT, int ACCEL, int TV_U, int NT>
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (FH_TUNE_TV_NT: 0 none, 1 both, 2 stores only, 3 loads only)
+template <int IDENT, int ACCEL, int TV_U, int NT, int NB = 1>
 __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
+  constexpr int NTL = NT & 1, NTS = (NT >> 1) & 1;
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -918,10 +927,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
   double u1[6] = {0, 0, 0, 0, 0, 0};                              // c = coef  : dxdg, dg2, xh2, gsum, gmax, f   (ACCEL only)
   double fs = 0.0;
 
-  auto row_of = [&](int off) -> uint32_t {                        // (i0 + off) mod H, periodic
-    const int64_t Hh = (int64_t)p.H;
-    return (uint32_t)((((int64_t)i0 + off) % Hh + Hh) % Hh);
-  };
+  auto row_of = [&](int off) -> uint32_t { return tv_wrap_row(i0, off, p.H); };   // (i0 + off) mod H, periodic
   auto div_at = [&](d2 me, d2 below) -> double {                  // div of one field at (row, col) given the row below; right neighbour by shuffle
     const double right_y = tvz_from_right(me.y);
     const double a0 = sub_nofma(below.x, me.x);                   // roll(Y0, -1, axis 0) - Y0
@@ -938,19 +944,26 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
   double rn0_3 = 0.0, rn1_3 = 0.0;             // r_new of row s-3 (both candidates)
 
   const int total = (int)rows + 4;             // rows i0-2 .. i0+rows+1
-  for (int t0 = 0; t0 < total; t0 += TV_U) {
-    d2 xv1[TV_U], xv0[TV_U];
-    double bv[TV_U];
-    uint64_t npix[TV_U];
+  // One TRIP = TV_U consecutive rows.  load_trip issues a trip's loads (rows past the chunk are clamped: they re-read its last
+  // row and are never consumed); eat_trip runs stages A-D on a landed trip.  The empty asm statements pin the issue order
+  // (hipcc otherwise sinks every load to just ahead of its first use, i.e. nothing stays in flight across trips).
+  struct Trip { d2 x1[TV_U]; d2 x0[TV_U]; double b[TV_U]; };
+  auto load_trip = [&](Trip& T, int t0) {
 #pragma unroll
     for (int q = 0; q < TV_U; ++q) {
       const int s = min(t0 + q, total - 1) - 2;                   // clamp past the chunk (loads stay in bounds, rows not consumed)
-      npix[q] = (uint64_t)row_of(s) * p.W + cw;
-      xv1[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p1) + npix[q]);
-      bv[q] = load_f64<NT>(p.b + npix[q]);
-      xv0[q] = (d2){0.0, 0.0};
-      if (lag) xv0[q] = load_stream<NT>(reinterpret_cast<const d2*>(p.p0) + npix[q]);
+      const uint64_t npix = (uint64_t)row_of(s) * p.W + cw;
+      T.x1[q] = load_stream<NTL>(reinterpret_cast<const d2*>(p.p1) + npix);
+      T.b[q] = load_f64<NTL>(p.b + npix);
+      T.x0[q] = (d2){0.0, 0.0};
+      if (lag) T.x0[q] = load_stream<NTL>(reinterpret_cast<const d2*>(p.p0) + npix);
     }
+    asm volatile("" ::: "memory");
+  };
+  auto eat_trip = [&](const Trip& T, int t0) {
+    const d2 (&xv1)[TV_U] = T.x1;
+    const d2 (&xv0)[TV_U] = T.x0;
+    const double (&bv)[TV_U] = T.b;
 #pragma unroll
     for (int q = 0; q < TV_U; ++q) {
       const int s = t0 + q - 2;                                    // relative row that arrives now
@@ -973,7 +986,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
             xh.y = fwd_point(x0v.y, g0v.y, p.tau);
             const d2 xp = IDENT ? xh : tv_ball(xh);
             if (own && s >= 1 && s <= (int)rows) {                 // row s-1 in [0, rows)
-              store_d2<NT>(reinterpret_cast<d2*>(p.pn) + (uint64_t)(i0 + s - 1) * p.W + c, xp);
+              store_d2<NTS>(reinterpret_cast<d2*>(p.pn) + (uint64_t)(i0 + s - 1) * p.W + c, xp);
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 const double dx = sub_nofma(xp[e], x0v[e]);
@@ -1029,6 +1042,25 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
         b2 = b1;
         P1a = xv1[q]; P0a = xv0[q]; b1 = bv[q];
       }
+    }
+    asm volatile("" ::: "memory");
+  };
+  if constexpr (NB == 3) {
+    // three rotating trips: two stay in flight behind the one being consumed -- the shape that sustains this read/write mix
+    // best in scripts/bench_mem/mixprobe.hip (in the burst form below the waves sit in s_waitcnt 65 % of their cycles)
+    Trip T0, T1, T2;
+    load_trip(T0, 0);
+    load_trip(T1, TV_U);
+    for (int t0 = 0; t0 < total; t0 += 3 * TV_U) {
+      load_trip(T2, t0 + 2 * TV_U); eat_trip(T0, t0);
+      load_trip(T0, t0 + 3 * TV_U); eat_trip(T1, t0 + TV_U);
+      load_trip(T1, t0 + 4 * TV_U); eat_trip(T2, t0 + 2 * TV_U);
+    }
+  } else {
+    for (int t0 = 0; t0 < total; t0 += TV_U) {                    // burst form (round 2): load a trip, consume it
+      Trip T0;
+      load_trip(T0, t0);
+      eat_trip(T0, t0);
     }
   }
   // partials per workgroup: [0] fs [1..4] v0..v3 [5] rdot [6..8] u0 dxdg, dg2, gsum [9..13] u1 dxdg, dg2, xh2, gsum, f  [14] u0 gmax [15] u1 gmax

@@ -21,7 +21,7 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
- TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE) = range(11)
+ TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE) = range(12)
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
 STORAGE = {"f64": DTYPE_F64, "f32": DTYPE_F32_STORAGE}
@@ -36,6 +36,8 @@ SIGNATURES = {
     "fh_device_count": (_i32, [C.POINTER(_i32)]),
     "fh_create": (_i32, [_i32, C.POINTER(_ctx)]),
     "fh_create_ex": (_i32, [_i32, C.POINTER(_i32), _i32, C.POINTER(_ctx)]),
+    "fh_shard_count": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_shard": (_i32, [_ctx, _i32, C.POINTER(_ctx), C.POINTER(_u64), C.POINTER(_u64)]),
     "fh_destroy": (_i32, [_ctx]),
     "fh_sync": (_i32, [_ctx]),
     "fh_set_tuning": (_i32, [_ctx, _i32, C.c_longlong]),
@@ -120,28 +122,65 @@ def comm_unique_id():
 
 
 class HipContext:
-    """One device context (stream, device-resident A, vectors, workspace).  Not thread-safe."""
+    """One context (stream, device-resident A, vectors, workspace) on one device -- or, with `devices=[...]`, one context over
+    several row blocks of A driven from this process (fh_create_ex, ndev > 1).  Not thread-safe."""
 
-    def __init__(self, device=0, storage="f64"):
+    def __init__(self, device=0, storage="f64", devices=None):
         """storage: "f64" (default) or "f32" -- the device copy of a dense A in float32 (opt-in throughput mode; vectors,
-        accumulation and scalars stay float64)."""
+        accumulation and scalars stay float64).
+        devices: list of device ids, one per row block (in-process row sharding): all different = one GPU each, sums over RCCL;
+        all equal = every block on that one GPU, sums by an in-library kernel (what a one-GPU box can run)."""
         self.lib = load_library()
         self._h = _ctx()
         if storage not in STORAGE:
             raise ValueError('storage must be "f64" or "f32"')
-        if storage == "f64":
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if not devices:
+                raise ValueError("devices must name at least one device")
+            ids = (_i32 * len(devices))(*devices)
+            _check(self.lib, self.lib.fh_create_ex(len(devices), ids, STORAGE[storage], C.byref(self._h)))
+            device = devices[0]
+        elif storage == "f64":
             _check(self.lib, self.lib.fh_create(int(device), C.byref(self._h)))
         else:
             ids = (_i32 * 1)(int(device))
             _check(self.lib, self.lib.fh_create_ex(1, ids, STORAGE[storage], C.byref(self._h)))
         self.device = int(device)
+        self.devices = devices
         self.storage = storage
         self._scal = np.zeros(NSCALARS)
         self._scal_p = self._scal.ctypes.data_as(_pd)
         self.sharded = False            # True once a multi-rank communicator is attached (comm_init)
 
+    @classmethod
+    def _borrowed(cls, lib, handle, device, storage):
+        """A view of a shard of a multi-device context (fh_shard): same methods, never destroyed from here."""
+        self = cls.__new__(cls)
+        self.lib, self._h, self.device, self.devices, self.storage = lib, handle, device, None, storage
+        self._scal = np.zeros(NSCALARS)
+        self._scal_p = self._scal.ctypes.data_as(_pd)
+        self.sharded = False
+        self._view = True
+        return self
+
+    def shard_count(self):
+        n = _i32(0)
+        self._call("fh_shard_count", C.byref(n))
+        return int(n.value)
+
+    def shard(self, k):
+        """(context view, row0, rows) of row block k; the view is valid while this context lives."""
+        h, r0, rows = _ctx(), _u64(0), _u64(0)
+        self._call("fh_shard", int(k), C.byref(h), C.byref(r0), C.byref(rows))
+        dev = self.devices[k] if self.devices else self.device
+        return HipContext._borrowed(self.lib, h, dev, self.storage), int(r0.value), int(rows.value)
+
     # ---- lifetime ------------------------------------------------------------------------------
     def close(self):
+        if getattr(self, "_view", False):           # a borrowed shard: owned by its multi-device context
+            self._h = _ctx()
+            return
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.fh_destroy(self._h)
             self._h = _ctx()

@@ -10,8 +10,9 @@
  * Conventions
  *   - every function returns 0 on success, otherwise a non-zero code (hipError_t / ncclResult_t
  *     value, or FH_E_*); fh_last_error() then describes it (thread-local string).
- *   - one fh_ctx per device per process; a context is NOT thread-safe; calls are synchronous from
- *     the caller's view (fh_fwd / fh_adj return once their scalars are on the host).
+ *   - a context is NOT thread-safe; calls are synchronous from the caller's view (fh_fwd / fh_adj
+ *     return once their scalars are on the host).  A context drives one device (fh_create), or --
+ *     fh_create_ex with ndev > 1 -- several row blocks of A in ONE process from one host thread.
  *   - the library copies on every set_* and never keeps a host pointer past the call; it owns all
  *     device memory behind fh_ctx until fh_destroy.
  *   - all arithmetic is IEEE float64 (the reference is float64 throughout).
@@ -85,25 +86,48 @@ enum fh_tuning_key {
   FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */
   FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
   FH_TUNE_NT_LOADS = 5,      /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
-  FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads in flight per lane (2, 4, 8; 0 = auto)  */
+  FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads per trip and lane (2, 4, 8; 0 = auto)  */
   FH_TUNE_TV_ROWS = 7,       /* stencil kernels: image rows per workgroup (0 = auto)                 */
-  FH_TUNE_TV_NT = 8,         /* stencil kernels: non-temporal loads/stores (default 0)               */
+  FH_TUNE_TV_NT = 8,         /* stencil kernels: 0 = default, 1 = non-temporal loads and stores (two-launch kernels and the z-streaming
+                                one-pass kernels; the z-free one-pass sweep never loads non-temporally: its halo columns and rows are
+                                re-read through L2), 2 = non-temporal stores (the z-free sweep's default), 3 = plain accesses      */
   FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h)   */
-  FH_TUNE_TV_ZFREE = 10      /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
+  FH_TUNE_TV_ZFREE = 10,     /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
                                 pixel); 0 = the round-1 kernels that stream z (56 / 80 B per pixel)                          */
+  FH_TUNE_TV_PIPE = 11       /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 = three rotating
+                                trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto        */
 };
 
 /* ---- library / context -------------------------------------------------------------- */
 const char* fh_last_error(void);
 int fh_device_count(int* count);
 int fh_create(int device, fh_ctx** out);
-/* SURVEY.md 8(b) form: device list + storage type of A.  One process drives one GPU (row sharding = one context per process,
- * fh_comm_init), so ndev must be 1.  dtype FH_DTYPE_F32_STORAGE keeps the device copy of A in float32 (rounded to nearest on
+/* SURVEY.md 8(b) form: device list + storage type of A.
+ *   ndev == 1: a plain single-device context (what fh_create returns).
+ *   ndev  > 1: IN-PROCESS ROW SHARDING (the op being sharded is `A @ x` / `A.T @ x`, fasta/linalg.py:41).  The
+ *     context owns one shard per entry of dev_ids; fh_set_matrix / fh_set_matrix_f32 / fh_generate_matrix split A into contiguous
+ *     row blocks (the first m mod ndev shards hold ceil(m/ndev) rows, the rest floor(m/ndev)), fh_set_loss_* and the m-side
+ *     vectors (FH_VEC_B, FH_VEC_Z) are split the same way, n-side vectors are replicated.  Every solver step then runs as: local
+ *     launch on each shard -> ONE sum over the shards -> n-side epilogue on each shard -> one host synchronisation; the scalar
+ *     block is identical on all shards and is returned from shard 0.  The call sequence, arguments and results of every other
+ *     entry point are those of a plain context (fh_set_stencil and fh_comm_* refuse: dense operator only, and the rows are
+ *     already sharded).
+ *       all dev_ids different: one GPU per shard; RCCL communicators from ncclCommInitAll, the sum is one grouped
+ *                              ncclAllReduce(n + 3 doubles) per shard over xGMI;
+ *       all dev_ids equal:     every shard on that one GPU, on one stream; the sum is an in-library kernel that adds the shards'
+ *                              buffers in shard order -- same arithmetic structure, runnable (and tested) on a one-GPU box.
+ *     (a mixture is FH_E_ARG.)  ndev <= 64.
+ * dtype FH_DTYPE_F32_STORAGE keeps the device copy of A in float32 (rounded to nearest on
  * upload / generation): half the bytes per pass; every vector, accumulation and scalar stays float64.  OPT-IN: the iterates
  * are those of the reference run on the ROUNDED matrix, i.e. they differ from the float64-matrix run by the rounding of A
  * (relative 6e-8 per entry; SURVEY.md section 7: <= 3e-7 on the iterates away from the chaotic regime).                  */
 enum fh_dtype { FH_DTYPE_F64 = 0, FH_DTYPE_F32_STORAGE = 1 };
 int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out);
+/* row blocks of a context (1 for a plain one); fh_shard lends shard k -- a complete single-device context that stays owned by
+ * `ctx` -- with the rows of the whole operator it holds: [row0, row0 + rows).  For diagnostics and tests (e.g. reading a
+ * replicated vector from every shard).                                                                                   */
+int fh_shard_count(fh_ctx* ctx, int* count);
+int fh_shard(fh_ctx* ctx, int k, fh_ctx** shard, uint64_t* row0, uint64_t* rows);
 int fh_destroy(fh_ctx* ctx);
 int fh_sync(fh_ctx* ctx);
 int fh_set_tuning(fh_ctx* ctx, int key, long long value);
@@ -175,7 +199,9 @@ int fh_commit(fh_ctx* ctx, int save_best);
  * adjoint=1: out(n) = A^H in(m).                                                                 */
 int fh_apply(fh_ctx* ctx, int adjoint, const double* in, double* out);
 
-/* ---- row sharding across GPUs: one process per GPU, RCCL communicator by rank ----------------- */
+/* ---- row sharding across PROCESSES: one process per GPU, RCCL communicator by rank (the in-process form is fh_create_ex
+ *      with ndev > 1; the two are not combined: these refuse a multi-device context, except fh_comm_count, which reports
+ *      its number of shards) ------------------------------------------------------------------------------------------ */
 /* writes an ncclUniqueId (128 bytes) -- rank 0 calls it and ships the bytes to the other ranks     */
 int fh_comm_unique_id(void* id128);
 int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
@@ -187,8 +213,10 @@ int fh_comm_destroy(fh_ctx* ctx);
 int fh_timing_enable(fh_ctx* ctx, int on);
 int fh_timing_get(fh_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
 int fh_timing_reset(fh_ctx* ctx);
-/* streaming-read ceiling: one read-only pass over the device copy of A in the product's own launch shape (groups of
- * 8 rows, <= 2 persistent workgroups per CU, non-temporal 16-byte loads, 16 loads in flight per lane), returns ms   */
+/* streaming-read ceiling: one read-only pass over the device copy of A by k_stream_probe<16,1> (csrc/fh_dense.h): one persistent
+ * workgroup per CU (FH_TUNE_FWD_GRID_CAP overrides), three rotating register buffers of 16 non-temporal 16-byte loads per lane
+ * (32 loads in flight behind the buffer being summed), loads + adds only; returns ms per pass.  A multi-device context
+ * measures shard 0's row block.                                                                                           */
 int fh_stream_read_ms(fh_ctx* ctx, int reps, double* ms_per_pass, uint64_t* bytes_per_pass);
 
 #ifdef __cplusplus

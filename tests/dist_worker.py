@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 
 import bench                                    # noqa: E402  (Group = the product's rendezvous helper)
 import fasta_python_amd as fa                   # noqa: E402
+from fasta_python_amd import hip                # noqa: E402
 from fasta_python_amd.linalg import LinearMap, _DeviceMap   # noqa: E402
 from tests.fake_ctx import FakeContext          # noqa: E402
 
@@ -35,21 +36,43 @@ def problem(seed, M=96, N=160, K=6, sigma=0.01, mu=0.02):
 
 
 class ShardedFakeContext(FakeContext):
-    """Row block of A on this rank; sums that fasta_hip.hip all-reduces with RCCL are all-reduced here with gloo."""
+    """Row block of A on this rank; sums that fasta_hip.hip all-reduces with RCCL are all-reduced here with gloo.
+
+    The one-pass entry points (step / step_accel) model csrc/fasta_hip.hip:dense_step: the launch's timeout word rides in the same
+    all-reduce as g1 and the loss sums, so EVERY rank sees the summed verdict and raises -- `inject_timeout_at` makes this rank's
+    k-th one-pass launch report a (local) timeout."""
     sharded = True
 
-    def __init__(self, Ak, allreduce):
+    def __init__(self, Ak, allreduce, fused_kind=0, inject_timeout_at=None):
         self.allreduce = allreduce
-        FakeContext.__init__(self, lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (Ak.shape[1],), (Ak.shape[0],))
+        self.inject_timeout_at = inject_timeout_at
+        self.one_pass_launches = 0
+        self.timeout_raised_at = None           # index of the one-pass launch whose summed timeout word was non-zero
+        FakeContext.__init__(self, lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (Ak.shape[1],), (Ak.shape[0],), fused_kind)
 
     def _f_sum(self, z):                        # fh_fwd: reduce_fsq_over_ranks; fh_adj: the 1-double all-reduce next to g1
         return float(self.allreduce(np.array([FakeContext._f_sum(self, z)]))[0])
 
+    def _verdict(self, scalars):
+        local = 1.0 if self.one_pass_launches == self.inject_timeout_at else 0.0
+        k = self.one_pass_launches
+        self.one_pass_launches += 1
+        if float(self.allreduce(np.array([local]))[0]) != 0.0:       # the word every rank reads back (scalars[15])
+            self.timeout_raised_at = k
+            raise hip.HipError("fused one-pass kernel: team hand-off timed out (injected)")
+        return scalars
+
+    def step(self, tau):
+        return self._verdict(FakeContext.step(self, tau))
+
+    def step_accel(self, tau, coef, restart):
+        return self._verdict(FakeContext.step_accel(self, tau, coef, restart))
+
 
 class ShardedFakeMap(_DeviceMap):
-    def __init__(self, Ak, allreduce):
+    def __init__(self, Ak, allreduce, fused_kind=0, inject_timeout_at=None):
         self.shape = Ak.shape
-        self.ctx = ShardedFakeContext(Ak, allreduce)
+        self.ctx = ShardedFakeContext(Ak, allreduce, fused_kind, inject_timeout_at)
         LinearMap.__init__(self, self.ctx.fwd_op, self.ctx.adj_op, (Ak.shape[1],), (Ak.shape[0],))
 
 
@@ -83,11 +106,24 @@ def main():
     np.random.seed(9)                                   # same Lipschitz probes on every rank
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        extra = {}
         if path == "driver":
             op = ShardedFakeMap(Ak, allreduce)
             ls, reg = fa.LeastSquares(bk), fa.Shrink(mu)
             c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, x0, **opts)
             assert op.ctx.calls["fwd"] + op.ctx.calls["pair"] > 0
+        elif path == "timeout":
+            # one-pass kernel on every launch (fused kind 1); rank 1's 4th one-pass launch times out LOCALLY.  Both ranks must
+            # drop the one-pass kernel in that same launch (solver.py:_forward) and go on with K-fwd / K-adj in lock step.
+            op = ShardedFakeMap(Ak, allreduce, fused_kind=1, inject_timeout_at=3 if grp.rank == 1 else None)
+            ls, reg = fa.LeastSquares(bk), fa.Shrink(mu)
+            solver = fa.FBSolver(op, ls, reg, x0, **opts).setup()
+            assert solver.mode == "always"
+            c = solver.run()
+            assert not solver.use_fused and op.ctx.timeout_raised_at == 3
+            assert op.ctx.calls["fwd"] > 0 and op.ctx.calls["adj"] > 0          # the two-launch path took over
+            extra = dict(timeout_raised_at=op.ctx.timeout_raised_at, fused_steps=solver.fused_steps,
+                         one_pass_launches=op.ctx.one_pass_launches, two_launch_fwd=op.ctx.calls["fwd"])
         else:
             Ashard = fa.LinearMap(lambda x: Ak @ x, lambda r: allreduce(Ak.T @ r), (A.shape[1],), (hi - lo,))
             f = lambda z: .5 * np.sqrt(float(allreduce(np.sum((z - bk) ** 2)))) ** 2
@@ -97,7 +133,7 @@ def main():
             c = fa.fasta(Ashard, f, gradf, g, proxg, x0, **opts)
     np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), residuals=c.residuals, stepsizes=c.stepsizes,
              objectives=c.objectives, iterates=c.iterates, solution=c.solution,
-             iteration_count=c.iteration_count, backtracks=c.backtracks)
+             iteration_count=c.iteration_count, backtracks=c.backtracks, **extra)
     grp.barrier()
     grp.close()
 

@@ -25,8 +25,9 @@ def test_apply_matches_numpy(m, n):
     x, y = rng.randn(n), rng.randn(m)
     op = fa.DenseMatrixMap(A)
     try:
-        np.testing.assert_allclose(op(x), A @ x, rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(op.H(y), A.T @ y, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.device_apply(x), A @ x, rtol=1e-12, atol=1e-12)                  # K-fwd (fh_apply)
+        np.testing.assert_allclose(op.device_apply(y, adjoint=True), A.T @ y, rtol=1e-12, atol=1e-12)    # K-adj
+        assert np.array_equal(op(x), A @ x) and np.array_equal(op.H(y), A.T @ y)     # host arrays: the reference's closures (linalg.py:41)
         with pytest.raises(AssertionError):
             op(np.zeros(n + 1))                                     # fasta/linalg.py:58
     finally:
@@ -41,8 +42,8 @@ def test_apply_all_kernel_variants(cpt, rows, nt):
     op = fa.DenseMatrixMap(A, tuning={hip.TUNE_ADJ_CPT: cpt, hip.TUNE_FWD_ROWS: rows, hip.TUNE_NT_LOADS: nt,
                                       hip.TUNE_LD_PAD: 32, hip.TUNE_ADJ_SLAB_ROWS: 40, hip.TUNE_FWD_GRID_CAP: 7})
     try:
-        np.testing.assert_allclose(op(x), A @ x, rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(op.H(y), A.T @ y, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.device_apply(x), A @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.device_apply(y, adjoint=True), A.T @ y, rtol=1e-12, atol=1e-12)
     finally:
         op.close()
 

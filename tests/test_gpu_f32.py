@@ -35,8 +35,9 @@ def test_operator_is_the_rounded_matrix(m, n):
     op = fa.DenseMatrixMap(A, storage="f32")
     try:
         assert np.array_equal(op.host_rows(0, m), A32)                       # upload rounds to nearest, read-back widens exactly
-        np.testing.assert_allclose(op(x), A32 @ x, rtol=1e-12, atol=1e-12 * np.abs(A32).max() * np.abs(x).sum())
-        np.testing.assert_allclose(op.H(y), A32.T @ y, rtol=1e-12, atol=1e-12 * np.abs(A32).max() * np.abs(y).sum())
+        np.testing.assert_allclose(op.device_apply(x), A32 @ x, rtol=1e-12, atol=1e-12 * np.abs(A32).max() * np.abs(x).sum())
+        np.testing.assert_allclose(op.device_apply(y, adjoint=True), A32.T @ y, rtol=1e-12, atol=1e-12 * np.abs(A32).max() * np.abs(y).sum())
+        assert np.array_equal(op(x), A32 @ x)                                # on host arrays: the rounded matrix as well
         with pytest.raises(AssertionError):
             op(np.zeros(n + 1))
     finally:
@@ -50,7 +51,7 @@ def test_float32_host_matrix_goes_in_without_a_float64_detour():
     op = fa.LinearMap.from_matrix(A32, storage="f32")
     try:
         assert np.array_equal(op.host_rows(0, 45), A32.astype(np.float64))
-        np.testing.assert_allclose(op(x), A32.astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(op.device_apply(x), A32.astype(np.float64) @ x, rtol=1e-12, atol=1e-12)
     finally:
         op.close()
     import ctypes as C

@@ -56,6 +56,37 @@ def test_two_rank_row_sharding_matches_single_rank(tmp_path, mode, path):
     np.testing.assert_allclose(r0["iterates"][:k + 1], want.iterates[:k + 1], rtol=1e-8, atol=1e-12)
 
 
+@pytest.mark.parametrize("mode", ["adaptive", "accelerated"])
+def test_one_rank_timing_out_makes_both_ranks_drop_the_one_pass_kernel_together(tmp_path, mode):
+    """the row-sharded one-pass step all-reduces its timeout word with g1, so a hand-off timeout on ONE rank must make
+    EVERY rank fall back to K-fwd / K-adj in the same launch -- otherwise their collective sequences diverge and the job hangs.
+    Rank 1's 4th one-pass launch is made to time out; both ranks must report it at launch 3, finish, and match the oracle."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode, "timeout"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    np.random.seed(5)
+    P = pr.sparse_least_squares(M=96, N=160, K=6)
+    opts = dict(tolerance=1e-6, evaluate_objective=True, record_iterates=True,
+                adaptive=(mode != "accelerated"), accelerate=(mode == "accelerated"))
+    np.random.seed(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for key in ("residuals", "stepsizes", "objectives", "solution", "iteration_count", "backtracks",
+                "timeout_raised_at", "fused_steps", "one_pass_launches", "two_launch_fwd"):
+        assert np.array_equal(r0[key], r1[key]), key
+    assert int(r0["timeout_raised_at"]) == 3 and int(r0["one_pass_launches"]) == 4 and int(r0["fused_steps"]) == 3
+    assert int(r0["iteration_count"]) == want.iteration_count and int(r0["backtracks"]) == want.backtracks
+    k = want.iteration_count
+    np.testing.assert_allclose(r0["residuals"][:k], want.residuals[:k], rtol=1e-8)
+    np.testing.assert_allclose(r0["iterates"][:k + 1], want.iterates[:k + 1], rtol=1e-8, atol=1e-12)
+
+
 def test_bench_starts_its_own_workers_from_a_bare_shell():
     """`python bench.py --gpus 2` with no torch.distributed.run environment: the script must launch its two workers itself
     (as a child process) and relay rank 0's single JSON line on stdout.  --plumbing-only keeps the GPU out of it."""
