@@ -16,9 +16,16 @@ anything touches HIP) and relay rank 0's line.
 Prints ONE JSON line (rank 0): the driver's contract fields, `roofline` (achieved = the bytes the EXECUTED
 algorithm must move / the dominant kernel's HIP-event time, so frac <= 1), `cpu_baseline`, and `extra`:
 the other BASELINE configs timed by the same code in the same process -- nnls (config 3), tv and
-tv_accelerated (config 4), lasso_two_launch (the two-launch structure), lasso_f32_storage (opt-in float32 storage of A),
-lasso_wide_131072 (the widest single-team-of-16 shape), and for N > 1 `config5_shard`
-(32768 rows per rank = BASELINE config 5's per-GPU shape).
+tv_accelerated (config 4; timed over >= 100 iterations after warming up INTO the backtracking regime, whatever --steps says),
+lasso_two_launch (the two-launch structure), lasso_f32_storage (opt-in float32 storage of A), lasso_wide_131072 (the widest
+single-team-of-16 shape), natural_run (configs 2 and 3 to tolerance 1e-5: iterations, loop and whole-call seconds),
+inproc_8_row_blocks (the same matrix as 8 row blocks driven from this one process: the single-call multi-device form,
+here with all blocks on this GPU), and for N > 1 `config5_shard` (32768 rows per rank = BASELINE config 5's per-GPU shape).
+`--inproc` runs the whole N-GPU job from ONE process (ShardedDenseMatrixMap over devices 0..N-1, or --devices).
+
+Rendezvous between ranks is torch.distributed (gloo) when torch is importable and a dependency-free TCP rendezvous
+(`SocketGroup`) otherwise; every wait is bounded, a rank that dies takes the job down (non-zero exit) instead of parking the
+others in a collective, and `ranks_seen != world` is an error.
 """
 import argparse
 import json
@@ -60,6 +67,15 @@ def parse(argv=None):
                     help="device storage of A: f64 (default, the headline) or f32 (opt-in throughput mode; arithmetic stays float64)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="rendezvous, broadcast, barrier and max-over-ranks only -- no GPU work (CPU rehearsal of --gpus N)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="drive all --gpus devices from ONE process (ShardedDenseMatrixMap, fh_create_ex ndev > 1) instead of one process per GPU")
+    ap.add_argument("--devices", default="", help="--inproc: comma list of device ids, one per row block (default 0..gpus-1; "
+                                                  "a repeated id, e.g. 0,0,0,0, puts every block on that GPU)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
+                    help="how `--gpus N` from a bare shell starts its workers: torch.distributed.run, or the built-in spawner with the "
+                         "TCP rendezvous (auto: torch when importable)")
+    ap.add_argument("--rdv-timeout", type=float, default=600.0, help="seconds any rendezvous wait may take before the job is abandoned")
+    ap.add_argument("--die-at-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank exits(3) after the first barrier
     return ap.parse_args(argv)
 
 
@@ -74,15 +90,52 @@ def _free_port():
     return port
 
 
-def self_launch(args, argv):
-    """`python bench.py --gpus N` from a bare shell: start N workers under torch.distributed.run as a CHILD process
-    (this process has made no HIP call and makes none) and let rank 0 print the line on the inherited stdout."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+def _worker_env(extra=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    env.update(extra or {})
+    return env
+
+
+def _torch_run_available():
+    import importlib.util
+    try:
+        return importlib.util.find_spec("torch") is not None and importlib.util.find_spec("torch.distributed.run") is not None
+    except (ImportError, ValueError):
+        return False
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell: start N workers as CHILD processes (this process has made no HIP call and
+    makes none) and let rank 0 print the line on the inherited stdout.  With torch: under torch.distributed.run.  Without (or
+    --launcher socket): N plain children that meet over the TCP rendezvous of SocketGroup; the parent watches them and, as
+    torch.distributed.run does, ends the others as soon as one fails -- a dead rank must not leave its peers in a collective."""
+    use_torch = args.launcher == "torch" or (args.launcher == "auto" and _torch_run_available())
+    if use_torch:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+        return subprocess.run(cmd, env=_worker_env()).returncode
+    port = _free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = _worker_env({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus),
+                           "FASTA_BENCH_RDV": f"127.0.0.1:{port}"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        time.sleep(0.05)
+        for pr in list(pending):
+            code = pr.poll()
+            if code is None:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:                  # exactly the processes started above
+                    other.terminate()
+    return rc
 
 
 class quiet_stdout:
@@ -100,10 +153,88 @@ class quiet_stdout:
         os.close(self.keep)
 
 
-class Group:
-    """Rendezvous/barrier plumbing: torch.distributed over gloo when launched with >1 rank."""
+class SocketGroup:
+    """Dependency-free rendezvous for the ranks of one node: rank 0 listens on FASTA_BENCH_RDV, the others connect; barrier,
+    byte broadcast and max-reduce are one round trip through rank 0.  Every wait is bounded by `timeout` seconds."""
 
-    def __init__(self):
+    def __init__(self, rank, world, addr, timeout):
+        import pickle
+        self.pickle = pickle
+        self.rank, self.world, self.local_rank = rank, world, int(os.environ.get("LOCAL_RANK", rank))
+        self.force, self.dist = False, self
+        host, port = addr.rsplit(":", 1)
+        self.peers = []
+        if rank == 0:
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host, int(port)))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                conn.settimeout(timeout)
+                by_rank[self._recv(conn)] = conn
+            srv.close()
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    self.conn = socket.create_connection((host, int(port)), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            self.conn.settimeout(timeout)
+            self._send(self.conn, rank)
+
+    def _send(self, conn, obj):
+        data = self.pickle.dumps(obj)
+        conn.sendall(len(data).to_bytes(8, "little") + data)
+
+    def _recv(self, conn):
+        def exact(k):
+            buf = b""
+            while len(buf) < k:
+                chunk = conn.recv(k - len(buf))
+                if not chunk:
+                    raise ConnectionError("a rank closed its rendezvous connection (it died?)")
+                buf += chunk
+            return buf
+        return self.pickle.loads(exact(int.from_bytes(exact(8), "little")))
+
+    def _gather_scatter(self, value, combine):
+        """rank 0 collects one value per rank, combines, sends the result back"""
+        if self.world == 1:
+            return combine([value])
+        if self.rank == 0:
+            out = combine([value] + [self._recv(c) for c in self.peers])
+            for c in self.peers:
+                self._send(c, out)
+            return out
+        self._send(self.conn, value)
+        return self._recv(self.conn)
+
+    def barrier(self):
+        self._gather_scatter(None, lambda vs: None)
+
+    def broadcast_bytes(self, payload):
+        return self._gather_scatter(payload, lambda vs: vs[0])
+
+    def max(self, value):
+        return float(self._gather_scatter(float(value), max))
+
+    def close(self):
+        for c in self.peers + ([self.conn] if self.rank else []):
+            c.close()
+
+
+class Group:
+    """Rendezvous/barrier plumbing: torch.distributed over gloo when launched with >1 rank (bounded waits)."""
+
+    def __init__(self, timeout=600.0):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,12 +242,13 @@ class Group:
         # FASTA_BENCH_FORCE_DIST=1 rehearses the multi-process plumbing (gloo + RCCL communicator) with one rank
         self.force = os.environ.get("FASTA_BENCH_FORCE_DIST") == "1"
         if self.world > 1 or self.force:
+            import datetime
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             with quiet_stdout():
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=timeout))
                 dist.barrier()
             self.dist, self.torch = dist, torch
 
@@ -143,18 +275,29 @@ class Group:
             self.dist.destroy_process_group()
 
 
+def make_group(timeout=600.0):
+    """The rendezvous this process was started under: FASTA_BENCH_RDV (bench.py's own spawner) -> SocketGroup, else torch/gloo."""
+    rdv = os.environ.get("FASTA_BENCH_RDV")
+    if rdv:
+        return SocketGroup(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), rdv, timeout)
+    return Group(timeout)
+
+
 def plumbing_only(args, grp):
     """CPU rehearsal of the N-rank launch: everything bench.py does between ranks except the GPU work."""
     token = grp.broadcast_bytes(bytes(range(128)) if grp.rank == 0 else None)
     assert token == bytes(range(128))
     grp.barrier()
+    if args.die_at_rank == grp.rank:                       # tests: a rank that dies mid-job must end the job, not hang it
+        os._exit(3)
     t0 = time.perf_counter()
     time.sleep(0.01 * (grp.rank + 1))
     grp.barrier()
     elapsed = grp.max(time.perf_counter() - t0)
     if grp.rank == 0:
         print(json.dumps({"plumbing_only": True, "n_gpus": grp.world, "ranks": grp.world, "max_elapsed_s": elapsed,
-                          "rows_per_rank": args.m // grp.world}))
+                          "rows_per_rank": args.m // grp.world, "rendezvous": type(grp).__name__,
+                          "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
     grp.close()
 
 
@@ -274,8 +417,9 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     import fasta_python_amd as fa
     from fasta_python_amd import synthetic
     ctx = A.ctx
-    m_local = A.Wshape[0]
+    m_local = A.Wshape[0]              # rows this PROCESS holds (all of them for an in-process sharded map)
     row0 = A.rows[0]
+    blocks = ctx.shard_count() if hasattr(ctx, "shard_count") else 1
     mu, sigma = 0.02, (0.005 if workload == "nnls" else 0.01)     # nn_least_squares.py:49 uses 0.005
     x_true = synthetic.sparse_signal(n, seed=1)
     b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
@@ -285,7 +429,8 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
                          max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
     np.random.seed(3)           # same Lipschitz probes on every rank
     t = timed_steps(solver, ctx, grp, warmup, steps)
-    by = dense_bytes(m_local, n, 4 if getattr(A, "storage", "f64") == "f32" else 8)
+    # per LAUNCH: a multi-device context launches once per row block (its timers add up launches and time over the blocks)
+    by = dense_bytes(m_local // blocks, n, 4 if getattr(A, "storage", "f64") == "f32" else 8)
     per = {"fasta_fwd(k_fwd_dense)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_dense)": t["k"]["adj"] + (by["adj"],),
            "fasta_step(k_fused_dense)": t["k"]["fused"] + (by["fused"],)}
     dom, table = kernel_table(per)
@@ -306,6 +451,32 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     }
 
 
+def natural_runs(A, n, m_total):
+    """the natural runs of configs 2 and 3 -- default options, tolerance 1e-5, through fasta() itself."""
+    import numpy as np
+    import fasta_python_amd as fa
+    from fasta_python_amd import synthetic
+    out = {}
+    x_true = synthetic.sparse_signal(n, seed=1)
+    for name, reg, sigma in (("lasso", fa.Shrink(0.02), 0.01), ("nnls", fa.NonNeg(), 0.005)):
+        b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=A.rows[0], m_total=m_total)
+        ls = fa.LeastSquares(b)
+        np.random.seed(3)
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = fa.fasta(A, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, tolerance=1e-5, backend="hip")
+        wall = time.perf_counter() - t0
+        k = c.iteration_count
+        loop = c.times[k] - c.times[0]
+        out[name] = {"iterations": int(k), "backtracks": int(c.backtracks), "loop_s": loop, "whole_call_s": wall,
+                     "iterations_per_s": k / loop, "final_residual": float(c.residuals[k - 1]),
+                     "rel_error_vs_x_true": float(np.linalg.norm(c.solution - x_true) / np.linalg.norm(x_true))}
+    out["note"] = ("fasta(A, ls.f, ls.gradf, reg.g, reg.prox, x0, tolerance=1e-5) on the resident matrix: loop_s = times[k] - times[0] "
+                   "(the reference's print_info span), whole_call_s adds the setup passes (Lipschitz probes, init) and the D2H of the solution")
+    return out
+
+
 def sub_result(r, workload):
     d = r["per_kernel"].get(r["dominant"], {}) if r["dominant"] else {}
     return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
@@ -314,11 +485,19 @@ def sub_result(r, workload):
             "per_kernel": r["per_kernel"]}
 
 
-def tv_bytes(P, accelerate):
+def tv_bytes(P, accelerate, zfree=True):
     """Algorithmic bytes per launch of the stencil kernels as executed: neither the gradient nor -- in the
-    one-pass kernel -- z is materialised.  One-pass: reads x0 16 + b 8, writes xprox 16 per pixel; with FISTA the iterate is
-    kept as (prox output, previous prox output, coefficient): reads 2 x 16 + 8, writes 16.  Two launches: 56 + 56 (+48 FISTA)."""
-    return {"fwd": 56 * P, "adj": (56 + (48 if accelerate else 0)) * P, "fused": (56 if accelerate else 40) * P}
+    z-free one-pass kernel -- z is materialised.  One-pass: reads x0 16 + b 8, writes xprox 16 per pixel; with FISTA the iterate is
+    kept as (prox output, previous prox output, coefficient): reads 2 x 16 + 8, writes 16.  The z-streaming one-pass kernels
+    (FH_TUNE_TV_ZFREE = 0) add a read and a write of z: 56 / 80.  Two launches: 56 + 56 (+48 FISTA)."""
+    fused = (56 if accelerate else 40) if zfree else (80 if accelerate else 56)
+    return {"fwd": 56 * P, "adj": (56 + (48 if accelerate else 0)) * P, "fused": fused * P}
+
+
+def tv_kernel_name(accelerate, zfree):
+    if zfree:
+        return "fasta_step_accel(k_tv_onepass<accel>)" if accelerate else "fasta_step(k_tv_onepass)"
+    return "fasta_step_accel(k_fused_tv_accel)" if accelerate else "fasta_step(k_fused_tv_step)"
 
 
 def run_tv(args, grp, steps, warmup, fused, accelerate):
@@ -332,9 +511,12 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
     M += 0.1 * np.random.standard_normal(M.shape)
     mu = 0.1
     A = fa.GradDivMap(M.shape, device=grp.local_rank)
+    zfree = True
     for item in filter(None, args.tune.split(",")):
         k, v = item.split("=")
         A.ctx.set_tuning(int(k), int(v))
+        if int(k) == 10:                               # FH_TUNE_TV_ZFREE: which one-pass kernel runs, hence its bytes and its name
+            zfree = bool(int(v))
     try:
         loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
         solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=not accelerate, accelerate=accelerate,
@@ -344,13 +526,16 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
     finally:
         A.close()
     P = side * side
-    by = tv_bytes(P, accelerate)
+    by = tv_bytes(P, accelerate, zfree)
     per = {"fasta_fwd(k_fwd_tv_step)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_tv_step)": t["k"]["adj"] + (by["adj"],),
-           ("fasta_step_accel(k_tv_onepass<accel>)" if accelerate else "fasta_step(k_tv_onepass)"): t["k"]["fused"] + (by["fused"],)}
+           tv_kernel_name(accelerate, zfree): t["k"]["fused"] + (by["fused"],)}
     dom, table = kernel_table(per)
     model_bytes = (steps * 136 + t["backtracks"] * 64) * P
     return {
         "value": steps / t["elapsed"], "ms_per_step": t["elapsed"] / steps * 1e3, "elapsed": t["elapsed"],
+        "steps": steps, "warmup": warmup,
+        # what a stretch of iterations WITHOUT backtracking runs at: every launch (one per iteration + one per backtrack) costs the same
+        "backtrack_free_value": (steps + t["backtracks"]) / t["elapsed"],
         "backtracks": t["backtracks"], "fused_steps": t["fused_steps"], "dominant": dom, "per_kernel": table,
         "loop_GB/s_wallclock": sum(v[1] * v[2] for v in per.values()) / t["elapsed"] / 1e9,
         "vs_materialised_model": {"bytes_per_iteration": 136 * P, "GB/s": model_bytes / t["elapsed"] / 1e9,
@@ -383,11 +568,13 @@ def tv_line(args, r, accelerate):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("FASTA_BENCH_FORCE_DIST") != "1":
+    # every launch mode (own spawner, torch.distributed.run started by somebody else, one process): before anything loads HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC; RCCL fails without it
+    if args.gpus > 1 and not args.inproc and "WORLD_SIZE" not in os.environ and os.environ.get("FASTA_BENCH_FORCE_DIST") != "1":
         raise SystemExit(self_launch(args, argv))          # before any import that could initialise HIP
-    grp = Group()
-    if grp.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={grp.world}")
+    grp = make_group(args.rdv_timeout)
+    if grp.world != (1 if args.inproc else args.gpus):
+        raise SystemExit(f"--gpus {args.gpus}{' --inproc (one process)' if args.inproc else ''} but WORLD_SIZE={grp.world}")
     if args.plumbing_only:
         return plumbing_only(args, grp)
 
@@ -410,9 +597,17 @@ def main(argv=None):
     for item in filter(None, args.tune.split(",")):
         k, v = item.split("=")
         tuning[int(k)] = int(v)
+    inproc_devices = None
+    if args.inproc:
+        inproc_devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        assert len(inproc_devices) == args.gpus, "--devices must name one device per row block (--gpus of them)"
 
     def shard(m_all, storage=None):
-        """This rank's row block of the synthetic (m_all x n) matrix, generated in HBM, with the RCCL communicator attached."""
+        """This rank's row block of the synthetic (m_all x n) matrix, generated in HBM, with the RCCL communicator attached
+        (--inproc: the whole matrix as row blocks over the devices of this one process)."""
+        if inproc_devices is not None:
+            return fa.ShardedDenseMatrixMap.synthetic(m_all, n, seed=0, scale=synthetic.lasso_scale(m_all, n), devices=inproc_devices,
+                                                      tuning=tuning, storage=storage or args.storage)
         rows = m_all // grp.world
         A = fa.DenseMatrixMap.synthetic(rows, n, seed=0, scale=synthetic.lasso_scale(m_all, n), row0=grp.rank * rows,
                                         m_total=m_all, device=grp.local_rank, tuning=tuning, storage=storage or args.storage)
@@ -425,11 +620,14 @@ def main(argv=None):
     A = shard(m_total)
     ctx = A.ctx
     ranks_seen = ctx.comm_count()
+    want_ranks = args.gpus if (args.inproc or grp.world > 1) else 1
+    if ranks_seen != want_ranks:
+        raise SystemExit(f"row sharding over {want_ranks} GPUs was asked for but the communicator reports {ranks_seen} rank(s)")
     main_r = run_dense(args, grp, A, m_total, n, args.workload, fused, args.steps, args.warmup, args.accelerate)
     dom = main_r["dominant"]
     d = main_r["per_kernel"][dom]
     traffic, traffic_src = (pmc_traffic("k_fused_dense" if "fused" in dom else ("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>"))
-                            if (m_total, n, grp.world) == (65536, 65536, 1) else (None, None))
+                            if (m_total, n, args.gpus) == (65536, 65536, 1) else (None, None))
     ceil_ms, ceil_bytes = ctx.stream_read_ms(3)
     fused_kind = ctx.fused_supported()
 
@@ -438,7 +636,7 @@ def main(argv=None):
         "metric": "FBS iterations/sec + achieved HBM GB/s, dense A m=n=65536, LASSO prox",
         "value": main_r["value"],
         "unit": "iterations/s",
-        "n_gpus": grp.world,
+        "n_gpus": args.gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": main_r["ms_per_step"],
@@ -449,13 +647,14 @@ def main(argv=None):
         "data": "synthetic",
         "config": {"workload": f"{names[0]} dense A {m_total}x{n} {'float64' if args.storage == 'f64' else 'float32-storage'}, {names[1]} prox, "
                                f"{'FISTA' if args.accelerate else 'adaptive FBS'} with backtracking"
-                               + (f", row-sharded over {grp.world} GPUs ({m_local} rows each)" if grp.world > 1 else ""),
+                               + (f", row-sharded over {args.gpus} GPUs ({m_total // args.gpus} rows each"
+                                  f"{', one process driving all devices ' + str(inproc_devices) if args.inproc else ', one process per GPU'})" if args.gpus > 1 else ""),
                    "m": m_total, "n": n, "prox": "shrink" if args.workload == "lasso" else "nonneg", "mu": main_r["mu"],
                    "backtracks_in_timed_steps": main_r["backtracks"],
                    "iteration_structure": ("one launch per iteration (one-pass kernel: both directions from a single read of A)"
                                            if main_r["fused_steps"] else "two launches per iteration (K-fwd, K-adj)"),
                    "fused_supported": fused_kind,        # 0 = this shape has no one-pass kernel (two passes over A per iteration)
-                   "parallelism": f"row-shard x{grp.world}" if grp.world > 1 else "1 GPU"},
+                   "parallelism": (f"row-shard x{args.gpus}" + (" in-process" if args.inproc else "")) if args.gpus > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
@@ -479,13 +678,13 @@ def main(argv=None):
             extra["lasso_two_launch"] = sub_result(r, f"LASSO {m_total}x{n}, two launches per iteration (K-fwd + K-adj, the north-star structure)")
         r = run_dense(args, grp, A, m_total, n, "nnls", fused, args.steps, args.warmup)
         extra["nnls"] = sub_result(r, f"NNLS {m_total}x{n} (BASELINE config 3), non-negativity prox, same matrix")
-        if grp.world > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
+        if args.gpus > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
             # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
             A.close()
-            A = shard(32768 * grp.world)
+            A = shard(32768 * args.gpus)
             ctx = A.ctx
-            r = run_dense(args, grp, A, 32768 * grp.world, n, "lasso", fused, args.steps, args.warmup)
-            s = sub_result(r, f"LASSO {32768 * grp.world}x{n} row-sharded over {grp.world} GPUs, 32768 rows each "
+            r = run_dense(args, grp, A, 32768 * args.gpus, n, "lasso", fused, args.steps, args.warmup)
+            s = sub_result(r, f"LASSO {32768 * args.gpus}x{n} row-sharded over {args.gpus} GPUs, 32768 rows each "
                               f"(BASELINE config 5 is this at 8 GPUs)")
             s["comm_avg_ms"], s["ranks_seen"] = r["comm_avg_ms"], ctx.comm_count()
             extra["config5_shard"] = s
@@ -511,12 +710,35 @@ def main(argv=None):
                     extra["lasso_wide_131072"] = s
                 finally:
                     Aw.close()
+            # TV: warmed up INTO the backtracking regime (the adaptive run starts backtracking after ~40 iterations and then does so
+            # every second or third one) and timed over 100 iterations, whatever --steps / --warmup say
             for key, acc in (("tv", False), ("tv_accelerated", True)):
-                r = run_tv(args, grp, args.steps, args.warmup, "auto", acc)
+                r = run_tv(args, grp, max(args.steps, 100), max(args.warmup, 60), "auto", acc)
                 s = sub_result(r, f"TV denoising {args.image}x{args.image} (BASELINE config 4), "
                                   f"{'FISTA (test_modes accelerated)' if acc else 'adaptive FBS'}")
+                s["steps"], s["warmup"] = r["steps"], r["warmup"]
+                s["backtrack_free_value"] = r["backtrack_free_value"]
+                s["note"] = ("value = iterations/s over the timed steps INCLUDING their backtracking launches; backtrack_free_value = "
+                             "launches/s = the rate of a stretch without backtracking (what round 2 reported)")
                 s["vs_materialised_model"] = r["vs_materialised_model"]
                 extra[key] = s
+            extra["natural_run"] = natural_runs(A, n, m_total)
+            # the single-call multi-device form (ShardedDenseMatrixMap, fh_create_ex ndev > 1) on this one GPU: the same matrix as 8
+            # row blocks of 8192 x 65536, all on this device -- what the row-sharded plumbing (8 local launches, the sum over the
+            # blocks, 8 n-side epilogues, one synchronisation) costs next to the single launch of the headline
+            if (m_total, n) == (65536, 65536):
+                A.close()
+                A8 = fa.ShardedDenseMatrixMap.synthetic(m_total, n, seed=0, scale=synthetic.lasso_scale(m_total, n),
+                                                        devices=[grp.local_rank] * 8, tuning=tuning)
+                try:
+                    r = run_dense(args, grp, A8, m_total, n, "lasso", fused, args.steps, args.warmup)
+                    s = sub_result(r, f"LASSO {m_total}x{n} as 8 row blocks of {m_total // 8} rows driven from one process "
+                                      f"(ShardedDenseMatrixMap, all blocks on this GPU, sums in block order by an in-library kernel)")
+                    s["row_blocks"], s["comm_avg_ms"] = A8.ctx.comm_count(), r["comm_avg_ms"]
+                    extra["inproc_8_row_blocks"] = s
+                finally:
+                    A8.close()
+                A = shard(m_total)                     # (the CPU baseline below pulls the matrix back from HBM)
     if extra:
         result["extra"] = extra
     if grp.rank == 0 and grp.world == 1 and not args.no_cpu_baseline and args.workload == "lasso" and not args.accelerate and args.storage == "f64":

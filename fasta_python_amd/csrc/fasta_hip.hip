@@ -17,8 +17,11 @@
 #include "fh_prox.h"
 #include "fh_fused.h"
 
-// the one-pass kernel's variants are compiled in fh_fused_part.hip (four groups, in parallel): here they are only declared
-// (-DFH_SINGLE_TU, used by the asm / resources / prof targets, instantiates everything in this unit instead)
+// The one-pass kernel's variants: ONE table, fh_fused_instances.inc, drives (a) the explicit instantiations, compiled in four
+// parallel groups by fh_fused_part.hip, (b) their `extern template` declarations here and (c) the host dispatch table kFusedTable
+// below -- a shape that fused_shape() can produce but the table lacks is an error at launch (and a failure of
+// tests/test_cabi_cpu.py, which walks every n), never a silent fall to some default instantiation.
+// (-DFH_SINGLE_TU, used by the asm / resources / prof targets, instantiates everything in this unit instead.)
 #ifndef FH_SINGLE_TU
 #define FH_FUSED_DECLARE(P, PI, T, X, NB, F) extern template __global__ void k_fused_dense<P, 1, PI, T, X, NB, F>(const FusedP);
 #define FUSED_INST_0 FH_FUSED_DECLARE
@@ -31,6 +34,19 @@
 #undef FUSED_INST_2
 #undef FUSED_INST_3
 #endif
+struct FusedEntry { int ppt, pipe, team, xlds, nbo, f32; void (*kernel)(const FusedP); };
+#define FH_FUSED_ROW(P, PI, T, X, NB, F) {P, PI, T, X, NB, F, k_fused_dense<P, 1, PI, T, X, NB, F>},
+#define FUSED_INST_0 FH_FUSED_ROW
+#define FUSED_INST_1 FH_FUSED_ROW
+#define FUSED_INST_2 FH_FUSED_ROW
+#define FUSED_INST_3 FH_FUSED_ROW
+static const FusedEntry kFusedTable[] = {
+#include "fh_fused_instances.inc"
+};
+#undef FUSED_INST_0
+#undef FUSED_INST_1
+#undef FUSED_INST_2
+#undef FUSED_INST_3
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -581,6 +597,10 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_PIPE must be 0 (auto), 1 (load a trip, consume it) or 3 (three rotating trip buffers; 2 is taken as 3)");
       c->tv_pipe = (int)value; return 0;
     case FH_TUNE_TV_ZFREE:
+      // while the iterate is kept lazily (one-pass FISTA on the stencil), z-free steps rotate their image buffers without ever
+      // writing them: the z-streaming kernel would read stale images after a switch
+      if (c->lazy && (value ? 1 : 0) != c->tv_zfree)
+        return fail(FH_E_STATE, "TV_ZFREE cannot change while a one-pass accelerated stencil solve is in flight (call fh_init / fh_set_vector(X0) first)");
       c->tv_zfree = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_VARIANT:
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
@@ -1168,88 +1188,87 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 //                slower, but still 1.8x the two-launch path)
 // FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536;
 // bit 16: n in (65536, 131072] as in round 1 (16 members x 16 pieces in registers, exchange in line).
-struct FusedShape { int ppt, team, pipe; };
-static FusedShape fused_shape(fh_ctx* c) {
-  FusedShape none = {0, 0, 0};
-  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL || c->ld % 2 || c->n == 0) return none;
-  // 16-byte pieces per row that hold data (the row stride c->ld may be padded): 2 columns each, 4 in float32 storage
-  const uint64_t pieces = c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2;
-  if (pieces > c->ld / (c->f32 ? 4 : 2)) return none;
+// FusedShape = the template key of k_fused_dense (PPT, PIPE, TEAM, XLDS, NBO) for a row of n columns: a pure function of
+// (n, row stride, storage, FH_TUNE_FUSED_VARIANT, #CUs), exported as fh_fused_shape so that it can be checked without a GPU.
+struct FusedShape { int ppt, team, pipe, xlds, nbo; };
+static FusedShape fused_shape_for(uint64_t n, uint64_t ld, int f32, int variant, int ncu) {
+  const FusedShape none = {0, 0, 0, 0, 0};
+  if (ld % 2 || n == 0) return none;
+  // 16-byte pieces per row that hold data (the row stride ld may be padded): 2 columns each, 4 in float32 storage
+  const uint64_t pieces = f32 ? round_up(n, 32) / 4 : round_up(n, 16) / 2;
+  if (pieces > ld / (f32 ? 4 : 2)) return none;
   FusedShape sh = none;
-  if (c->f32) {
+  if (f32) {
     // float32 storage: the same byte rule (a member's piece of a row is 5..8 pieces per lane = 20-32 KiB per workgroup per
     // row), i.e. twice the columns per team size: n <= 8192 one member, then 2 / 4 / 8 / 16 members up to n = 131072.  A piece
     // carries four columns, so the x and g1 slices cost twice the registers per piece: from 5 pieces on the x slice lives in
-    // LDS and 3-4 row buffers rotate (launch_fused_f32), which hipcc allocates without spilling.
+    // LDS and 4 (5-6 pieces) or 3 (7-8 pieces) row buffers rotate, posting one row ahead -- the spill-free combinations
+    // (-Rpass-analysis=kernel-resource-usage)
     for (int team = 1; team <= 16; team *= 2) {
       if (pieces > (uint64_t)team * FH_WG * 8) continue;
       int ppt = (int)((pieces + (uint64_t)team * FH_WG - 1) / ((uint64_t)team * FH_WG));
       if (ppt == 3) ppt = 4;
       if (team > 1 && ppt < 5) ppt = 5;          // (cannot happen: pieces > (team/2)*256*8 already means ppt >= 5)
-      sh = {ppt, team, 1};
+      const int xl = ppt >= 5 ? 1 : 0;
+      sh = {ppt, team, 1, xl, xl ? (ppt <= 6 ? 4 : 3) : 0};
       break;
     }
-    if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;
-    return sh;
-  }
-  if (pieces <= (uint64_t)1 * FH_WG * 8 && !(c->fused_variant & 8)) {
+  } else if (pieces <= (uint64_t)1 * FH_WG * 8 && !(variant & 8)) {
     int ppt = (int)((pieces + FH_WG - 1) / FH_WG);                       // n <= 4096: a workgroup owns whole rows, 256 "teams" of one
     if (ppt == 3) ppt = 4;
-    sh = {ppt, 1, 1};
-  } else if (pieces > (uint64_t)1 * FH_WG * 8 && pieces <= (uint64_t)2 * FH_WG * 8 && !(c->fused_variant & 8)) {
-    sh = {(int)((pieces + 2 * FH_WG - 1) / (2 * FH_WG)), 2, 1};        // n in (4096, 8192]: 2 members x 5..8 pieces, 128 teams
-  } else if (pieces > (uint64_t)2 * FH_WG * 8 && pieces <= (uint64_t)4 * FH_WG * 8 && !(c->fused_variant & 8)) {
-    sh = {(int)((pieces + 4 * FH_WG - 1) / (4 * FH_WG)), 4, 1};        // n in (8192, 16384]: 4 members x 5..8 pieces, 64 teams
+    sh = {ppt, 1, 1, 0, 0};
+  } else if (pieces > (uint64_t)1 * FH_WG * 8 && pieces <= (uint64_t)2 * FH_WG * 8 && !(variant & 8)) {
+    sh = {(int)((pieces + 2 * FH_WG - 1) / (2 * FH_WG)), 2, 1, 0, 0};  // n in (4096, 8192]: 2 members x 5..8 pieces, 128 teams
+  } else if (pieces > (uint64_t)2 * FH_WG * 8 && pieces <= (uint64_t)4 * FH_WG * 8 && !(variant & 8)) {
+    sh = {(int)((pieces + 4 * FH_WG - 1) / (4 * FH_WG)), 4, 1, 0, 0};  // n in (8192, 16384]: 4 members x 5..8 pieces, 64 teams
   } else if (pieces <= (uint64_t)8 * FH_WG * 8) {
     int ppt = (int)((pieces + 8 * FH_WG - 1) / (8 * FH_WG));
     if (ppt == 3) ppt = 4;
-    sh = {ppt, 8, 1};
-  } else if (pieces == (uint64_t)8 * FH_WG * 16 && (c->fused_variant & 8)) {
-    sh = {16, 8, 0};
+    sh = {ppt, 8, 1, 0, 0};
+  } else if (pieces == (uint64_t)8 * FH_WG * 16 && (variant & 8)) {
+    sh = {16, 8, 0, 0, 0};
   } else if (pieces <= (uint64_t)16 * FH_WG * 8) {
-    sh = {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2};
+    sh = {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2, 0, 0};       // 16 members: posts run two rows ahead of the polls
   } else if (pieces <= (uint64_t)16 * FH_WG * 16) {
-    // n in (65536, 131072]: 16 members x 9..16 pieces, posts one row ahead, x slice in LDS
-    // (variant bit 16: the round-1 shape -- 16 pieces, x slice in registers, 3 row buffers, exchange in line)
+    // n in (65536, 131072]: 16 members x 9..16 pieces POSTING ONE ROW AHEAD, made possible by keeping the x slice in LDS (the
+    // registers hold 3-4 row buffers -- the largest count hipcc allocates without spilling -- and the g1 slice); measured against
+    // the round-1 in-line shape in profiles/r02_fused_wide.txt: 131072 columns 6.41 -> 4.80 ms (7.16 TB/s), 70000: 5.80 -> 2.87 ms
+    // (variant bit 16: that round-1 shape -- 16 pieces, x slice in registers, 3 row buffers, exchange in line)
     const int ppt = (int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG));
-    sh = (c->fused_variant & 16) ? FusedShape{16, 16, 0} : FusedShape{ppt, 16, 1};
+    sh = (variant & 16) ? FusedShape{16, 16, 0, 0, 0} : FusedShape{ppt, 16, 1, 1, ppt <= 10 ? 4 : 3};
   } else if (pieces <= (uint64_t)32 * FH_WG * 16) {
     // n in (131072, 262144]: 32 members (a whole XCD per team, 8 teams) x 9..16 pieces, same schedule
-    sh = {(int)((pieces + 32 * FH_WG - 1) / (32 * FH_WG)), 32, 1};
+    const int ppt = (int)((pieces + 32 * FH_WG - 1) / (32 * FH_WG));
+    sh = {ppt, 32, 1, 1, ppt <= 10 ? 4 : 3};
   }
-  if (!sh.ppt || c->ncu < sh.team || c->ncu % sh.team) return none;     // one workgroup per CU, whole teams only
+  if (!sh.ppt || ncu < sh.team || ncu % sh.team) return none;     // one workgroup per CU, whole teams only
   return sh;
 }
+static const FusedEntry* fused_lookup(const FusedShape& sh, int f32) {
+  for (const FusedEntry& e : kFusedTable)
+    if (e.ppt == sh.ppt && e.pipe == sh.pipe && e.team == sh.team && e.xlds == sh.xlds && e.nbo == sh.nbo && e.f32 == f32) return &e;
+  return nullptr;
+}
+static FusedShape fused_shape(fh_ctx* c) {
+  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL) return FusedShape{0, 0, 0, 0, 0};
+  return fused_shape_for(c->n, c->ld, c->f32, c->fused_variant, c->ncu);
+}
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
+// diagnostic / test entry: the shape chosen for n columns and whether its kernel is instantiated (no device needed)
+extern "C" int fh_fused_shape(uint64_t n, int dtype, int variant, int ncu, int* shape5, int* instantiated) {
+  if (!shape5 || !instantiated) return fail(FH_E_ARG, "null argument");
+  const int f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
+  const FusedShape sh = fused_shape_for(n, round_up(n, f32 ? 32 : 16), f32, variant, ncu);
+  shape5[0] = sh.ppt; shape5[1] = sh.pipe; shape5[2] = sh.team; shape5[3] = sh.xlds; shape5[4] = sh.nbo;
+  *instantiated = sh.ppt && fused_lookup(sh, f32) ? 1 : 0;
+  return 0;
+}
 // the one-pass launch beats K-fwd + K-adj once its fixed cost is amortised: wide rows, or at least 8 Mi elements
 // (profiles/r02_fused_crossover.txt; 32 Mi in round 1, when every launch still refilled its hand-off slots from the host)
 static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 23); }
 
-// the prox kind travels in p.px.kind (run-time switch in the kernel's n-side prologue); FH_PROX_* == PX_* numerically
-template <int PPT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0>
-static void launch_fused_p(fh_ctx* c, const FusedP& p, unsigned grid, int kind) {
-  (void)kind;
-  // the fused kernels always stream A with non-temporal loads (+10 % in the dense sweeps); only NT = 1 is built
-  k_fused_dense<PPT, 1, PIPE, TEAM, XLDS, NBO><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-}
-// float32-storage twin (shapes: fused_shape); from 5 pieces per lane the x slice lives in LDS and 4 (5-6 pieces) or 3 (7-8
-// pieces) row buffers rotate, posting one row ahead -- the spill-free combinations (-Rpass-analysis=kernel-resource-usage)
-template <int PPT, int TEAM>
-static void launch_fused_f32(fh_ctx* c, const FusedP& p, unsigned grid) {
-  constexpr int XL = PPT >= 5 ? 1 : 0;
-  constexpr int NB = XL ? (PPT <= 6 ? 4 : 3) : 0;
-  k_fused_dense<PPT, 1, 1, TEAM, XL, NB, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-}
-template <int TEAM>
-static void launch_fused_f32_ppt(fh_ctx* c, const FusedP& p, unsigned grid, int ppt) {
-  switch (ppt) {
-    case 5: launch_fused_f32<5, TEAM>(c, p, grid); break;
-    case 6: launch_fused_f32<6, TEAM>(c, p, grid); break;
-    case 7: launch_fused_f32<7, TEAM>(c, p, grid); break;
-    default: launch_fused_f32<8, TEAM>(c, p, grid); break;
-  }
-}
-
+// (the prox kind travels in p.px.kind: a run-time switch in the kernel's n-side prologue; FH_PROX_* == PX_* numerically.  The
+// one-pass kernels always stream A with non-temporal loads, +10 % in the dense sweeps: only NT = 1 is built.)
 // operands of one fused launch; fh_step takes them from the solver state, fh_init / fh_gradient_at pass their own
 struct FusedIO {
   const double* x0; const double* g0; double* xhat; double* xp; double* z; double* g1;
@@ -1267,6 +1286,10 @@ static inline void fused_after(fh_ctx* c) { if (c->hscal[15] != 0.0) c->slots_si
 static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   const FusedShape sh = fused_shape(c);
   if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 262144 and a scalar-separable prox)");
+  const FusedEntry* k_fused_dense_entry = fused_lookup(sh, c->f32);
+  if (!k_fused_dense_entry)
+    return fail(FH_E_STATE, "fused one-pass step: no instantiation for PPT %d, PIPE %d, TEAM %d, XLDS %d, NBO %d, F32 %d (fh_fused_instances.inc)",
+                sh.ppt, sh.pipe, sh.team, sh.xlds, sh.nbo, c->f32);
   FusedP p;
   p.A = c->A; p.ld = c->ld; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
@@ -1306,8 +1329,10 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   {
     // signature of everything the slot layout depends on; 0 = "refill" (set after a timed-out launch, see fused_after)
     uint64_t sig = fh_mix((uint64_t)(uintptr_t)c->slotbuf ^ fh_mix(slots_elems * 131 + (uint64_t)sh.team * 7 + p.nteams)) | 1ull;
-    if (sh.team > 1 && sig != c->slots_sig) {
-      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
+    if (sig != c->slots_sig) {
+      // (a team of one exchanges nothing through the slots, but its grid barrier and error word are the same counters: a launch
+      // that timed out in another shape must not leave them armed for it)
+      if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
       HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
       c->slots_sig = sig;
       c->slots_parity = 0;
@@ -1316,90 +1341,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
     c->slots_parity ^= 1;
   }
-  if (c->f32) {
-    if (sh.team == 1) {
-      switch (sh.ppt) {
-        case 1: launch_fused_f32<1, 1>(c, p, grid); break;
-        case 2: launch_fused_f32<2, 1>(c, p, grid); break;
-        case 4: launch_fused_f32<4, 1>(c, p, grid); break;
-        default: launch_fused_f32_ppt<1>(c, p, grid, sh.ppt); break;
-      }
-    } else if (sh.team == 2) launch_fused_f32_ppt<2>(c, p, grid, sh.ppt);
-    else if (sh.team == 4) launch_fused_f32_ppt<4>(c, p, grid, sh.ppt);
-    else if (sh.team == 8) launch_fused_f32_ppt<8>(c, p, grid, sh.ppt);
-    else launch_fused_f32_ppt<16>(c, p, grid, sh.ppt);
-  } else if (sh.team == 1) {
-    switch (sh.ppt) {
-      case 1: launch_fused_p<1, 1, 1>(c, p, grid, io.kind); break;
-      case 2: launch_fused_p<2, 1, 1>(c, p, grid, io.kind); break;
-      case 4: launch_fused_p<4, 1, 1>(c, p, grid, io.kind); break;
-      case 5: launch_fused_p<5, 1, 1>(c, p, grid, io.kind); break;
-      case 6: launch_fused_p<6, 1, 1>(c, p, grid, io.kind); break;
-      case 7: launch_fused_p<7, 1, 1>(c, p, grid, io.kind); break;
-      default: launch_fused_p<8, 1, 1>(c, p, grid, io.kind); break;
-    }
-  } else if (sh.team == 2) {
-    switch (sh.ppt) {
-      case 5: launch_fused_p<5, 1, 2>(c, p, grid, io.kind); break;
-      case 6: launch_fused_p<6, 1, 2>(c, p, grid, io.kind); break;
-      case 7: launch_fused_p<7, 1, 2>(c, p, grid, io.kind); break;
-      default: launch_fused_p<8, 1, 2>(c, p, grid, io.kind); break;
-    }
-  } else if (sh.team == 4) {
-    switch (sh.ppt) {
-      case 5: launch_fused_p<5, 1, 4>(c, p, grid, io.kind); break;
-      case 6: launch_fused_p<6, 1, 4>(c, p, grid, io.kind); break;
-      case 7: launch_fused_p<7, 1, 4>(c, p, grid, io.kind); break;
-      default: launch_fused_p<8, 1, 4>(c, p, grid, io.kind); break;
-    }
-  } else if (sh.team == 8 && sh.pipe > 0) {
-    switch (sh.ppt) {
-      case 1: launch_fused_p<1, 1, 8>(c, p, grid, io.kind); break;
-      case 2: launch_fused_p<2, 1, 8>(c, p, grid, io.kind); break;
-      case 4: launch_fused_p<4, 1, 8>(c, p, grid, io.kind); break;
-      case 5: launch_fused_p<5, 1, 8>(c, p, grid, io.kind); break;
-      case 6: launch_fused_p<6, 1, 8>(c, p, grid, io.kind); break;
-      case 7: launch_fused_p<7, 1, 8>(c, p, grid, io.kind); break;
-      default: launch_fused_p<8, 1, 8>(c, p, grid, io.kind); break;
-    }
-  } else if (sh.team == 8) {
-    launch_fused_p<16, 0, 8>(c, p, grid, io.kind);
-  } else if (sh.team == 16 && sh.pipe > 0 && sh.ppt <= 8) {       // 16 members: posts run two rows ahead of the polls
-    switch (sh.ppt) {
-      case 5: launch_fused_p<5, 2, 16>(c, p, grid, io.kind); break;
-      case 6: launch_fused_p<6, 2, 16>(c, p, grid, io.kind); break;
-      case 7: launch_fused_p<7, 2, 16>(c, p, grid, io.kind); break;
-      default: launch_fused_p<8, 2, 16>(c, p, grid, io.kind); break;
-    }
-  } else if (sh.pipe == 0) {
-    launch_fused_p<16, 0, 16>(c, p, grid, io.kind);
-  } else if (sh.team == 32) {
-    switch (sh.ppt) {
-      case 9:  launch_fused_p<9, 1, 32, 1, 4>(c, p, grid, io.kind); break;
-      case 10: launch_fused_p<10, 1, 32, 1, 4>(c, p, grid, io.kind); break;
-      case 11: launch_fused_p<11, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-      case 12: launch_fused_p<12, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-      case 13: launch_fused_p<13, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-      case 14: launch_fused_p<14, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-      case 15: launch_fused_p<15, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-      default: launch_fused_p<16, 1, 32, 1, 3>(c, p, grid, io.kind); break;
-    }
-  } else {
-    // wide rows, n in (65536, 131072]: 16 members x 9..16 pieces POSTING ONE ROW AHEAD, made possible by keeping the x slice in
-    // LDS (the registers hold 3-4 row buffers and the g1 slice).  Buffer counts are the largest that hipcc allocates without
-    // spilling to scratch (-Rpass-analysis=kernel-resource-usage); measured against the round-1 in-line shape in
-    // profiles/r02_fused_wide.txt: 131072 columns 6.41 -> 4.80 ms (7.16 TB/s), 70000 columns 5.80 -> 2.87 ms.
-    switch (sh.ppt) {
-      case 9:  launch_fused_p<9, 1, 16, 1, 4>(c, p, grid, io.kind); break;
-      case 10: launch_fused_p<10, 1, 16, 1, 4>(c, p, grid, io.kind); break;
-      case 11: launch_fused_p<11, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-      case 12: launch_fused_p<12, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-      case 13: launch_fused_p<13, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-      case 14: launch_fused_p<14, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-      case 15: launch_fused_p<15, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-      default: launch_fused_p<16, 1, 16, 1, 3>(c, p, grid, io.kind); break;
-    }
-  }
+  k_fused_dense_entry->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_fused_shape": (_i32, [_u64, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_fwd_adj": (_i32, [_ctx, _dbl, _pd]),
     "fh_step": (_i32, [_ctx, _dbl, _pd]),
     "fh_step_accel": (_i32, [_ctx, _dbl, _dbl, _i32, _pd]),
@@ -112,6 +113,16 @@ def device_count():
     n = _i32(0)
     _check(lib, lib.fh_device_count(C.byref(n)))
     return n.value
+
+
+def fused_shape(n, storage="f64", variant=2, ncu=256):
+    """((pieces per lane, posting distance, team members, x slice in LDS, row buffers), instantiated) of the one-pass kernel for
+    rows of n columns; all zeros = no one-pass kernel for that width.  Host-only (works without a GPU)."""
+    lib = load_library()
+    shape = (_i32 * 5)()
+    inst = _i32(0)
+    _check(lib, lib.fh_fused_shape(int(n), STORAGE[storage], int(variant), int(ncu), shape, C.byref(inst)))
+    return tuple(shape), bool(inst.value)
 
 
 def comm_unique_id():

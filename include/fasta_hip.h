@@ -182,6 +182,11 @@ int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
  * fh_fused_supported: 0 = no (n > 262144, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
  * 8 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
+/* Which variant of the one-pass kernel serves rows of n columns -- shape5 = {pieces per lane, posting distance, team members,
+ * x slice in LDS, row buffers} (all 0: no one-pass kernel for this width) -- and whether that variant is compiled into the
+ * library (csrc/fh_fused_instances.inc).  A pure host function: no device needed.  dtype: fh_dtype; variant: FH_TUNE_FUSED_VARIANT
+ * bits; ncu: compute units (256 on MI355X).                                                                                */
+int fh_fused_shape(uint64_t n, int dtype, int variant, int ncu, int* shape5, int* instantiated);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
 /* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, also row-sharded): as fh_step, plus
  * x1 = xprox + c*(xprox - x_accel0) and the gradient taken at z1 + c*(z1 - z_accel0) with c = coef, or 0 when restart != 0

@@ -60,3 +60,27 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_every_row_width_resolves_to_an_instantiated_one_pass_kernel():
+    """The one-pass kernel's dispatch is a table (csrc/fh_fused_instances.inc) shared by the instantiations and the host: for EVERY
+    row width n = 1 .. 262144, both storages and the A/B variant bits, the shape fused_shape_for() picks must be compiled in --
+    there is no default instantiation to fall to.  Beyond 262144 columns there is no one-pass kernel (shape all zeros)."""
+    import ctypes as C
+    lib = hip.load_library()
+    shape = (C.c_int * 5)()
+    inst = C.c_int(0)
+    seen = set()
+    for dtype in (hip.DTYPE_F64, hip.DTYPE_F32_STORAGE):
+        for variant in (2, 0, 2 | 8, 2 | 16):
+            step = 1 if variant == 2 else 37                  # every n for the default variant, a coprime stride for the A/B bits
+            for n in list(range(1, 262145, step)) + [4096, 8192, 16384, 32768, 65536, 131072, 262144]:
+                assert lib.fh_fused_shape(n, dtype, variant, 256, shape, C.byref(inst)) == 0
+                if dtype == hip.DTYPE_F32_STORAGE and n > 131072:
+                    assert tuple(shape) == (0, 0, 0, 0, 0)                  # float32 storage: teams up to 16 members
+                    continue
+                assert shape[0] > 0 and inst.value == 1, (n, dtype, variant, tuple(shape))
+                assert shape[2] * 256 * shape[0] * (4 if dtype else 2) >= n      # the team covers the row
+                seen.add((dtype,) + tuple(shape))
+    assert lib.fh_fused_shape(262145, hip.DTYPE_F64, 2, 256, shape, C.byref(inst)) == 0 and tuple(shape) == (0, 0, 0, 0, 0)
+    assert len(seen) >= 60                                              # ... and nearly the whole table is reachable

@@ -265,6 +265,64 @@ def test_lost_partial_times_out_instead_of_hanging_and_the_solver_falls_back():
     np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
 
 
+def _pair_reference(op, b, mu, x0, tau, accel):
+    """fh_fwd + fh_adj from a fresh state: scalars and vectors the one-pass launch must reproduce"""
+    c = _state(op, b, mu, x0)
+    s = c.fwd(tau)
+    coef = 0.25 if accel else 0.0
+    a = c.adj(tau, accel, coef)
+    n, m = x0.size, b.size
+    return s, a, {k: c.get_vector(k, n) for k in (hip.VEC_XPROX, hip.VEC_G1, hip.VEC_X1)}, c.get_vector(hip.VEC_Z, m)
+
+
+def _assert_step_matches(c, got, ref, n, m):
+    s, a, vecs, z = ref
+    for k in (hip.S_FSQ, hip.S_DXG0, hip.S_DX2, hip.S_XH2, hip.S_G02, hip.S_GSUM, hip.S_GMAX):
+        np.testing.assert_allclose(got[k], s[k], rtol=1e-12, atol=1e-300, err_msg=f"fwd scalar {k}")
+    for k in (hip.S_DXDG, hip.S_DG2, hip.S_FSQ_ADJ):
+        np.testing.assert_allclose(got[k], a[k], rtol=1e-10, atol=1e-18, err_msg=f"adj scalar {k}")
+    assert np.array_equal(c.get_vector(hip.VEC_XPROX, n), vecs[hip.VEC_XPROX])
+    np.testing.assert_allclose(c.get_vector(hip.VEC_Z, m), z, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), vecs[hip.VEC_G1], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(c.get_vector(hip.VEC_X1, n), vecs[hip.VEC_X1], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("after", ["same_shape", "team_of_one", "other_team_count"])
+def test_one_pass_kernel_recovers_on_the_same_context_after_a_timed_out_launch(after):
+    """a timed-out launch leaves hand-off slots un-posted / un-armed and the barrier counters armed; the host must refill
+    them before the next one-pass launch on that context.  Sabotage one launch (fault-injection bit 64), clear the bit, then run
+    the one-pass kernel again -- at BOTH slot parities (two consecutive launches), plain and accelerated -- in the same team shape,
+    in a team-of-one shape (which exchanges nothing through the slots but shares the counters) and with a different number of
+    teams; every launch must equal fh_fwd + fh_adj."""
+    import time
+    rng = np.random.RandomState(11)
+    m, n = 96, 4096
+    A = rng.randn(m, n) / 40
+    b, x0 = rng.randn(m), rng.randn(n) * 0.05
+    tau, mu = 0.3, 0.02
+    op = fa.DenseMatrixMap(A)
+    try:
+        refs = {acc: _pair_reference(op, b, mu, x0, tau, acc) for acc in (False, True)}
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8)              # 8 members per team at n = 4096
+        c = _state(op, b, mu, x0)
+        _assert_step_matches(c, c.step(tau), refs[False], n, m)       # healthy launch first (slot parity flips)
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8 | 64)
+        c = _state(op, b, mu, x0)
+        t0 = time.time()
+        with pytest.raises(hip.HipError):
+            c.step(tau)
+        assert time.time() - t0 < 5.0
+        variant = {"same_shape": 2 | 8, "team_of_one": 2, "other_team_count": (2 | 8) | (4 << 16)}[after]     # high half: rows-per-team floor
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, variant)
+        for launch in range(4):                                       # parities 0, 1, 0, 1; plain, plain, accelerated, accelerated
+            accel = launch >= 2
+            c = _state(op, b, mu, x0)
+            got = c.step_accel(tau, 0.25, False) if accel else c.step(tau)
+            _assert_step_matches(c, got, refs[accel], n, m)
+    finally:
+        op.close()
+
+
 def test_setup_passes_use_the_one_pass_kernel_at_large_n():
     """fh_init / fh_gradient_at: z = A x and g = A^T(z - b) from one read of A when n >= 32768."""
     rng = np.random.RandomState(8)

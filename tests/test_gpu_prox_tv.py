@@ -373,3 +373,30 @@ def test_z_free_steps_can_be_followed_by_two_launch_steps():
     finally:
         a.close()
         b.close()
+
+
+def test_zfree_switch_is_refused_while_the_accelerated_iterate_is_kept_lazily():
+    """in one-pass FISTA mode the z-free sweep rotates its image buffers without writing them, so switching
+    FH_TUNE_TV_ZFREE to 0 mid-solve would make the z-streaming kernel read stale images: the library refuses (FH_E_STATE) until
+    the next fh_init / fh_set_vector(X0); setting the value it already has stays allowed."""
+    rng = np.random.RandomState(6)
+    H_, W_ = 40, 90
+    op = fa.GradDivMap((H_, W_))
+    try:
+        c = op.ctx
+        c.set_loss_lsq(rng.randn(H_, W_))
+        c.set_prox(hip.PROX_TVBALL)
+        c.set_vector(hip.VEC_X0, rng.randn(H_, W_, 2) * 0.5)
+        c.init()
+        c.step_accel(0.2, 0.0, True)
+        c.commit(False)
+        c.set_tuning(hip.TUNE_TV_ZFREE, 1)                      # no change: fine
+        with pytest.raises(hip.HipError, match="TV_ZFREE"):
+            c.set_tuning(hip.TUNE_TV_ZFREE, 0)
+        c.step_accel(0.2, 0.3, True)                            # the solve goes on undisturbed
+        c.set_vector(hip.VEC_X0, np.zeros((H_, W_, 2)))         # a new start lifts the restriction
+        c.set_tuning(hip.TUNE_TV_ZFREE, 0)
+        c.init()
+        c.step_accel(0.2, 0.0, True)
+    finally:
+        op.close()

@@ -101,6 +101,51 @@ def test_bench_starts_its_own_workers_from_a_bare_shell():
     assert out["max_elapsed_s"] >= 0.02                 # the slower rank's time (max over ranks)
 
 
+def _bare_env(**extra):
+    drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FASTA_BENCH_RDV", "HSA_ENABLE_IPC_MODE_LEGACY")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(extra)
+    return env
+
+
+def test_bench_socket_launcher_needs_no_torch():
+    """`--launcher socket`: bench.py's own spawner + TCP rendezvous (what `--gpus N` falls back to when torch cannot be imported):
+    same single JSON line, max over ranks, and the IPC mode the pool needs exported to every worker."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--plumbing-only", "--launcher", "socket"],
+                         capture_output=True, text=True, timeout=120, env=_bare_env(), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["ranks"] == 3 and out["rendezvous"] == "SocketGroup" and out["max_elapsed_s"] >= 0.03
+    assert out["hsa_enable_ipc_mode_legacy"] == "0"
+
+
+def test_bench_exports_the_ipc_mode_when_somebody_else_launches_it():
+    """The driver starts `torch.distributed.run ... bench.py --gpus N` itself: the workers must still get
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (set at the top of main(), before anything loads HIP), not only under bench.py's own launcher."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_bare_env(OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert out["hsa_enable_ipc_mode_legacy"] == "0" and out["rendezvous"] == "Group" and out["ranks"] == 2
+
+
+@pytest.mark.parametrize("launcher", ["socket", "torch"])
+def test_a_rank_that_dies_ends_the_job_instead_of_hanging_it(launcher):
+    """Rank 1 exits mid-job (after the first barrier).  The job must END with a non-zero status within the rendezvous timeout --
+    the launcher takes the surviving rank down (or its next barrier fails) -- and print no result line."""
+    import time
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--launcher", launcher,
+                          "--die-at-rank", "1", "--rdv-timeout", "20"],
+                         capture_output=True, text=True, timeout=240, env=_bare_env(), cwd=ROOT)
+    assert res.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
