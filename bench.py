@@ -29,6 +29,7 @@ others in a collective, and `ranks_seen != world` is an error.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -57,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--accelerate", action="store_true", help="FISTA (workload tv / lasso / nnls)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the nnls / tv / two-launch sub-results")
+    ap.add_argument("--skip-extra", default="", help="comma list of sub-results to skip (e.g. inproc: the two in-process row-block runs, "
+                                                     "whose launches of the headline kernel on SMALLER row blocks would otherwise be "
+                                                     "averaged into the same rocprofv3 kernel-stats row)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of A the CPU baseline runs on (0 = all)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-repeats", type=int, default=3)
@@ -471,7 +475,9 @@ def natural_runs(A, n, m_total):
         loop = c.times[k] - c.times[0]
         out[name] = {"iterations": int(k), "backtracks": int(c.backtracks), "loop_s": loop, "whole_call_s": wall,
                      "iterations_per_s": k / loop, "final_residual": float(c.residuals[k - 1]),
-                     "rel_error_vs_x_true": float(np.linalg.norm(c.solution - x_true) / np.linalg.norm(x_true))}
+                     # (plain sums, not np.linalg.norm: a BLAS call here wakes OpenBLAS's worker threads, whose busy-wait under the box's
+                     # CPU quota stalls the main thread for tens of ms a few iterations into the NEXT solve -- scripts/natural_run.py)
+                     "rel_error_vs_x_true": math.sqrt(float(np.sum((c.solution - x_true) ** 2)) / float(np.sum(x_true ** 2)))}
     out["note"] = ("fasta(A, ls.f, ls.gradf, reg.g, reg.prox, x0, tolerance=1e-5) on the resident matrix: loop_s = times[k] - times[0] "
                    "(the reference's print_info span), whole_call_s adds the setup passes (Lipschitz probes, init) and the D2H of the solution")
     return out
@@ -726,7 +732,7 @@ def main(argv=None):
             # the single-call multi-device form (ShardedDenseMatrixMap, fh_create_ex ndev > 1) on this one GPU: the same matrix as 8
             # row blocks of 8192 x 65536, all on this device -- what the row-sharded plumbing (8 local launches, the sum over the
             # blocks, 8 n-side epilogues, one synchronisation) costs next to the single launch of the headline
-            if (m_total, n) == (65536, 65536):
+            if (m_total, n) == (65536, 65536) and "inproc" not in args.skip_extra.split(","):
                 A.close()
                 A8 = fa.ShardedDenseMatrixMap.synthetic(m_total, n, seed=0, scale=synthetic.lasso_scale(m_total, n),
                                                         devices=[grp.local_rank] * 8, tuning=tuning)
@@ -738,6 +744,20 @@ def main(argv=None):
                     extra["inproc_8_row_blocks"] = s
                 finally:
                     A8.close()
+                # BASELINE config 5's matrix ITSELF (262144 x 65536 float64 = 128 GiB: it fits one MI355X) as its 8 per-GPU shards of
+                # 32768 x 65536, all on this GPU one after the other.  NOT a scaling number: it is the full config-5 problem solved
+                # through the row-sharded code path on the hardware a one-GPU box has; an 8-GPU run does each block on its own device.
+                A5 = fa.ShardedDenseMatrixMap.synthetic(262144, n, seed=0, scale=synthetic.lasso_scale(262144, n),
+                                                        devices=[grp.local_rank] * 8, tuning=tuning)
+                try:
+                    r = run_dense(args, grp, A5, 262144, n, "lasso", fused, args.steps, args.warmup)
+                    s = sub_result(r, "LASSO 262144x65536 (BASELINE config 5's matrix) as its 8 row blocks of 32768 rows, all eight on THIS one GPU "
+                                      "(ShardedDenseMatrixMap with a repeated device id): every iteration runs the 8 per-GPU launches back to back")
+                    s["row_blocks"], s["comm_avg_ms"] = A5.ctx.comm_count(), r["comm_avg_ms"]
+                    s["per_block_launch_ms"] = s["avg_launch_ms"]
+                    extra["config5_matrix_on_one_gpu"] = s
+                finally:
+                    A5.close()
                 A = shard(m_total)                     # (the CPU baseline below pulls the matrix back from HBM)
     if extra:
         result["extra"] = extra

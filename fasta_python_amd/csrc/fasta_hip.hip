@@ -1,4 +1,5 @@
-// fasta_hip.hip -- host side of libfasta_hip.so (C ABI declared in include/fasta_hip.h).
+// fasta_hip.hip -- the C ABI of libfasta_hip.so (declared in include/fasta_hip.h): entry points only.  The context and its helpers are
+// in fh_host_ctx.h, the kernel launchers in fh_host_launch.h, the kernels in fh_dense.h / fh_tv.h / fh_prox.h / fh_fused.h.
 // gfx950 only.  No PyTorch, no rocBLAS: every device operation is a kernel from fh_dense.h / fh_tv.h,
 // plus RCCL (dlopen'ed on first use) for the row-sharded adjoint.
 #include <hip/hip_runtime.h>
@@ -48,374 +49,8 @@ static const FusedEntry kFusedTable[] = {
 #undef FUSED_INST_2
 #undef FUSED_INST_3
 
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code ? code : FH_E_ARG;
-}
-
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-#define FH_TRY(expr)          \
-  do {                        \
-    int r_ = (expr);          \
-    if (r_ != 0) return r_;   \
-  } while (0)
-
-extern "C" const char* fh_last_error(void) { return g_err; }
-
-// ------------------------------------------------------------------------------------------------
-// RCCL through dlopen (no link-time dependency; the single-GPU path never touches it)
-// ------------------------------------------------------------------------------------------------
-typedef struct { char internal[128]; } fh_nccl_uid;
-typedef void* fh_nccl_comm;
-struct RcclApi {
-  void* lib = nullptr;
-  int (*GetUniqueId)(fh_nccl_uid*) = nullptr;
-  int (*CommInitRank)(fh_nccl_comm*, int, fh_nccl_uid, int) = nullptr;
-  int (*CommInitAll)(fh_nccl_comm*, int, const int*) = nullptr;
-  int (*CommDestroy)(fh_nccl_comm) = nullptr;
-  int (*CommCount)(const fh_nccl_comm, int*) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, fh_nccl_comm, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
-static RcclApi g_rccl;
-static const int kNcclFloat64 = 8;   // ncclDouble
-static const int kNcclSum = 0;       // ncclSum
-
-static int rccl_load() {
-  if (g_rccl.lib) return 0;
-  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
-  for (const char* nm : names) {
-    g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (g_rccl.lib) break;
-  }
-  if (!g_rccl.lib) return fail(FH_E_RCCL, "cannot dlopen librccl: %s", dlerror());
-#define SYM(field, name)                                                      \
-  *(void**)(&g_rccl.field) = dlsym(g_rccl.lib, name);                         \
-  if (!g_rccl.field) return fail(FH_E_RCCL, "librccl lacks symbol %s", name)
-  SYM(GetUniqueId, "ncclGetUniqueId");
-  SYM(CommInitRank, "ncclCommInitRank");
-  SYM(CommInitAll, "ncclCommInitAll");
-  SYM(CommDestroy, "ncclCommDestroy");
-  SYM(CommCount, "ncclCommCount");
-  SYM(AllReduce, "ncclAllReduce");
-  SYM(GroupStart, "ncclGroupStart");
-  SYM(GroupEnd, "ncclGroupEnd");
-  SYM(GetErrorString, "ncclGetErrorString");
-#undef SYM
-  return 0;
-}
-#define NCCL_TRY(expr)                                                                        \
-  do {                                                                                        \
-    int r_ = (expr);                                                                          \
-    if (r_ != 0) return fail(20000 + r_, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
-  } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------------
-enum { OP_NONE = 0, OP_DENSE = 1, OP_STENCIL = 2 };
-
-struct fh_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int op = OP_NONE;
-  bool op_pending_stencil = false;
-  uint64_t m = 0, n = 0;     // logical (local) rows / columns of A   (stencil: m = H*W, n = 2*H*W)
-  uint64_t mp = 0, ld = 0;   // padded rows, device leading dimension in elements (dense)
-  int f32 = 0;               // storage of A: 0 = float64, 1 = float32 (opt-in, fh_create_ex; vectors and arithmetic stay float64)
-  uint64_t nv = 0, mv = 0;   // allocated n-side / m-side vector lengths (doubles)
-  uint64_t H = 0, W = 0;
-  double* A = nullptr;
-  // n-side
-  // iterate pool: X[xi] = x0, X[ti] = where the next x1 lands, X[bi] = best-quality iterate (may alias X[xi]):
-  // the best iterate is tracked by index, never copied (a 1 GiB copy per improving iteration at 8192^2 TV)
-  double* X[3] = {nullptr, nullptr, nullptr};
-  int xi = 0, ti = 1, bi = 0;
-  double* P[2] = {nullptr, nullptr};   // prox outputs: x_accel1 / x_accel0
-  double* G[2] = {nullptr, nullptr};   // g0 / g1
-  double* xhat = nullptr;
-  double* T[4] = {nullptr, nullptr, nullptr, nullptr};
-  int pc = 0, gc = 0, zc = 0;
-  bool last_accel = false;
-  // m-side
-  double* b = nullptr;
-  double* Z[2] = {nullptr, nullptr};
-  double* zt = nullptr;
-  double* ZX[2] = {nullptr, nullptr};   // stencil + FISTA: extrapolated z' (the residual source of the next g0)
-  int zxc = 0;
-  const double* zcur = nullptr;         // stencil: z at the current x0 (Z[zc], or ZX[zxc] after an accelerated step)
-  // stencil + FISTA in ONE pass (k_fused_tv_accel): the iterate and its image are kept LAZILY as (P1, P0, c) and (Z1, Z0, c):
-  // x0 = P1 + c*(P1 - P0), z(x0) = Z1 + c*(Z1 - Z0) are formed inside the next sweep and never written.  Buffers are taken
-  // from the n-side pool {X[0], X[1], X[2], P[0], P[1]} and the m-side pool {Z[0], Z[1], ZX[0]} by index.
-  bool lazy = false;
-  int lq1 = 0, lq0 = 0, lqn = 0;        // last prox output, the one before, target of the next launch
-  int lz1 = 0, lz0 = 0, lzn = 0;        // their images
-  int lb1 = 0, lb0 = 0;                 // best-quality iterate = nq(lb1) + lbc*(nq(lb1) - nq(lb0)), by reference
-  double lbc = 0.0, lc = 0.0, lc_pending = 0.0;   // coefficient of the best iterate / of x0 / decided by the launch awaiting fh_commit
-  uint64_t commits = 0;                 // fh_commit calls since fh_init
-  // z-free one-pass stencil kernels (k_tv_onepass, the default): they neither read nor write z, so after such a step is
-  // committed the stored image of x0 is stale; the two-launch kernels recompute it on demand (one plain div pass)
-  int tv_zfree = 1;                     // FH_TUNE_TV_ZFREE
-  bool tvz_pending = false;             // the latest launch was z-free (its z_new exists only inside the kernel)
-  bool zcur_stale = false;
-  bool has_b = false;
-  int loss_kind = LOSS_LSQ;
-  // prox
-  int prox_kind = FH_PROX_IDENTITY;
-  double mu = 0.0, lo = 0.0, hi = 0.0;
-  // workspace
-  double* ws = nullptr;
-  size_t ws_bytes = 0;
-  unsigned* counters = nullptr;      // 4096 words, zeroed at creation; kernels leave them zero
-  double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
-  double* hscal = nullptr;           // pinned, device-mapped host block: single-GPU launches write their scalars here
-  double* hscal_dev = nullptr;       // device-side address of hscal
-  bool scal_mirrored = false;        // row-sharded runs: the last launch already copied the scalar block into hscal
-  // tuning
-  int fwd_rows = 0;          // 0 = auto
-  long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
-  int adj_slab = 0;          // 0 = auto
-  int adj_cpt = 0;           // 0 = auto
-  int ld_pad = 0;
-  int nt_loads = 1;
-  // stencil defaults measured on MI355X at 8192^2 (profiles/r01_tune_tv.txt): plain (not nt) accesses,
-  // 8 rows in flight, 32 rows per workgroup for K-fwd and 128 for the read-only K-adj
-  int tv_u = 0;              // 0 = auto: 8 for the kernels that stream z, 2 / 4 for the z-free one-pass sweeps (profiles/r02_tune_tv.txt)
-  int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
-  int tv_nt = 0;
-  int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
-  int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
-  int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
-  // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
-  // the host fills both with the sentinel only when this signature (workspace, layout) changes or a launch timed out
-  double* slotbuf = nullptr;     // dedicated allocation: the shared workspace `ws` is scribbled over by every other kernel
-  size_t slotbuf_bytes = 0;
-  uint64_t slots_sig = 0;
-  int slots_parity = 0;
-  // timing
-  bool timing = false;
-  hipEvent_t ev[FH_NKERNELS][2];
-  bool ev_pending[FH_NKERNELS] = {false, false, false, false, false};
-  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0, 0};
-  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0, 0};
-  // comm
-  fh_nccl_comm comm = nullptr;
-  int nranks = 1, rank = 0;
-  int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
-  // ---- in-process row sharding (fh_create_ex with ndev > 1; SURVEY.md 8(b)/(e): one host thread, one context per device) ----
-  // A context created over several devices is a SHELL: it owns one child context per entry of dev_ids (`shards`), each holding
-  // a contiguous block of rows of A and the matching slice of b / z, while x, g, xhat are replicated.  Every entry point of the
-  // C ABI runs on a shell as: local launches on every shard -> sum over the shards -> n-side epilogue on every shard -> ONE host
-  // synchronisation, scalars from shard 0.  The sum is one grouped ncclAllReduce per shard (communicators from
-  // ncclCommInitAll) when the device ids differ; when they REPEAT (several shards on one GPU: what a one-GPU box can run) all
-  // shards share one stream and k_sum_shards adds their buffers in shard order.
-  std::vector<fh_ctx*> shards;       // non-empty: this context is a shell
-  std::vector<uint64_t> shard_row0;  // first row of every shard, plus the total (size shards + 1)
-  fh_ctx* owner = nullptr;           // set in a shard
-  bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)
-  bool owns_stream = true;           // false in shards 1.. of an emulated group (they run on shard 0's stream)
-};
-
-#define FH_MAX_SHARDS 64
-static inline int nshards(fh_ctx* c) { return c->shards.empty() ? 1 : (int)c->shards.size(); }
-static inline fh_ctx* shard_of(fh_ctx* c, int k) { return c->shards.empty() ? c : c->shards[k]; }
-// a context whose launches leave the sums over rows to an exchange step: a rank of a multi-process run, or a shard of a shell
-static inline bool row_sharded(const fh_ctx* c) { return c->comm != nullptr || c->owner != nullptr; }
-
-static const int kCounterWords = 8192;
-enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_ADJ_CC = 16 };
-
-static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
-
-// device scratch that is released on every exit path (the HIP_TRY macros return early)
-struct DevBuf {
-  double* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
-static int use_device(fh_ctx* c) {
-  HIP_TRY(hipSetDevice(c->device));
-  return 0;
-}
-
-static void free_operator(fh_ctx* c) {
-  for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); free_operator(s); }
-  auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  fr(c->A);
-  for (int i = 0; i < 2; ++i) { fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
-  for (int i = 0; i < 3; ++i) fr(c->X[i]);
-  fr(c->xhat); fr(c->b); fr(c->zt); fr(c->ZX[0]); fr(c->ZX[1]);
-  for (int i = 0; i < 4; ++i) fr(c->T[i]);
-  fr(c->ws); c->ws_bytes = 0;
-  fr(c->slotbuf); c->slotbuf_bytes = 0; c->slots_sig = 0;
-  c->op = OP_NONE; c->has_b = false;
-}
-
-static int alloc_zero(fh_ctx* c, double** p, uint64_t elems) {
-  HIP_TRY(hipMalloc((void**)p, elems * sizeof(double)));
-  HIP_TRY(hipMemsetAsync(*p, 0, elems * sizeof(double), c->stream));
-  return 0;
-}
-
-static int alloc_vectors(fh_ctx* c) {
-  // +16 slack doubles on the n-side so sharded runs can append scalars to the all-reduce buffer
-  for (int i = 0; i < 2; ++i) {
-    FH_TRY(alloc_zero(c, &c->P[i], c->nv + 16));
-    FH_TRY(alloc_zero(c, &c->G[i], c->nv + 16));
-    FH_TRY(alloc_zero(c, &c->Z[i], c->mv + 16));
-  }
-  FH_TRY(alloc_zero(c, &c->xhat, c->nv + 16));
-  for (int i = 0; i < 3; ++i) FH_TRY(alloc_zero(c, &c->X[i], c->nv + 16));
-  for (int i = 0; i < 4; ++i) FH_TRY(alloc_zero(c, &c->T[i], c->nv + 16));
-  FH_TRY(alloc_zero(c, &c->b, c->mv + 16));
-  FH_TRY(alloc_zero(c, &c->zt, c->mv + 16));
-  if (c->op_pending_stencil) { FH_TRY(alloc_zero(c, &c->ZX[0], c->mv + 16)); FH_TRY(alloc_zero(c, &c->ZX[1], c->mv + 16)); }
-  c->pc = c->gc = c->zc = c->zxc = 0;
-  c->xi = 0; c->ti = 1; c->bi = 0;
-  c->zcur = nullptr;
-  return 0;
-}
-
-static int ensure_ws(fh_ctx* c, size_t bytes) {
-  if (bytes <= c->ws_bytes) return 0;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->ws) { HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
-  bytes = round_up(bytes, 1 << 20);
-  HIP_TRY(hipMalloc((void**)&c->ws, bytes));
-  c->ws_bytes = bytes;
-  return 0;
-}
-
-// ---- timing helpers ------------------------------------------------------------------------------
-static inline void t_begin(fh_ctx* c, int k) {
-  if (c->timing) { (void)hipEventRecord(c->ev[k][0], c->stream); }
-}
-static inline void t_end(fh_ctx* c, int k) {
-  if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
-}
-static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending event pairs
-  if (!c->shards.empty()) {        // shell: all shards (an emulated group shares one stream; its first shard's sync covers the rest)
-    for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); FH_TRY(finish(s)); }
-    return 0;
-  }
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->timing) {
-    for (int k = 0; k < FH_NKERNELS; ++k) {
-      if (!c->ev_pending[k]) continue;
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, c->ev[k][0], c->ev[k][1]));
-      c->tot_ms[k] += ms;
-      c->launches[k] += 1;
-      c->ev_pending[k] = false;
-    }
-  }
-  return 0;
-}
-
-// Where kernels write the FH_S_* block: straight into the mapped host block on one GPU (no D2H copy, the
-// stream sync alone publishes it); device memory when row-sharded, because RCCL reduces scalars in place.
-static inline double* scalar_out(fh_ctx* c) { return row_sharded(c) ? c->dscal : c->hscal_dev; }
-
-// row-sharded runs: the block lives in device memory (RCCL reduces into it); a 16-lane kernel forwards it to the mapped
-// host block -- a hipMemcpyAsync D2H of 128 bytes costs ~10 us more per iteration than this launch
-__global__ void k_forward_scalars(const double* src, double* dst) {
-  if (threadIdx.x < FH_NSCALARS) dst[threadIdx.x] = src[threadIdx.x];
-}
-
-static int fetch_scalars(fh_ctx* c, double* scalars) {
-  for (int k = 0; k < nshards(c); ++k) {
-    fh_ctx* s = shard_of(c, k);
-    const bool mirrored = s->scal_mirrored;
-    s->scal_mirrored = false;
-    if (row_sharded(s) && !mirrored) {
-      HIP_TRY(hipSetDevice(s->device));
-      k_forward_scalars<<<dim3(1), dim3(64), 0, s->stream>>>(s->dscal, s->hscal_dev);
-      HIP_TRY(hipGetLastError());
-    }
-  }
-  FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
-  // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors
-  if (scalars) memcpy(scalars, shard_of(c, 0)->hscal, FH_NSCALARS * sizeof(double));
-  return 0;
-}
-
-// ---- sums over the row blocks ------------------------------------------------------------------------------------------
-// out[i] = ((v0[i] + v1[i]) + v2[i]) + ... written back to every shard's buffer: the in-library, fixed-order replacement for the
-// all-reduce when several shards live on ONE device (device ids repeat; all shards share a stream, so plain ordering suffices)
-struct SumShardsP { double* v[FH_MAX_SHARDS]; int n; };
-__global__ __launch_bounds__(FH_WG) void k_sum_shards(const SumShardsP p, uint64_t count) {
-  for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < count; i += (uint64_t)gridDim.x * FH_WG) {
-    double acc = p.v[0][i];
-    for (int k = 1; k < p.n; ++k) acc += p.v[k][i];
-    for (int k = 0; k < p.n; ++k) p.v[k][i] = acc;
-  }
-}
-
-// Sum `count` doubles at sel(shard) -- and, in the same exchange, `count2` doubles at sel2(shard) -- over all row blocks, in place,
-// on every shard:
-//   plain context with a communicator (one process per GPU) -> ncclAllReduce on its stream;
-//   shell over distinct devices -> one grouped ncclAllReduce per shard (ncclCommInitAll communicators, one host thread);
-//   shell over a repeated device -> k_sum_shards;      plain context without a communicator -> nothing to do.
-template <typename Sel, typename Sel2>
-static int sum_over_shards(fh_ctx* c, Sel sel, size_t count, Sel2 sel2, size_t count2) {
-  if (c->shards.empty()) {
-    if (!c->comm) return 0;
-    t_begin(c, FH_K_COMM);
-    if (count2) NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllReduce(sel(c), sel(c), count, kNcclFloat64, kNcclSum, c->comm, c->stream));
-    if (count2) {
-      NCCL_TRY(g_rccl.AllReduce(sel2(c), sel2(c), count2, kNcclFloat64, kNcclSum, c->comm, c->stream));
-      NCCL_TRY(g_rccl.GroupEnd());
-    }
-    t_end(c, FH_K_COMM);
-    return 0;
-  }
-  if (c->emulated) {
-    fh_ctx* s0 = c->shards[0];
-    HIP_TRY(hipSetDevice(s0->device));
-    t_begin(s0, FH_K_COMM);
-    for (int pass = 0; pass < (count2 ? 2 : 1); ++pass) {
-      SumShardsP sp;
-      sp.n = (int)c->shards.size();
-      for (int k = 0; k < sp.n; ++k) sp.v[k] = pass ? sel2(c->shards[k]) : sel(c->shards[k]);
-      const uint64_t cnt = pass ? count2 : count;
-      const unsigned grid = (unsigned)std::min<uint64_t>((cnt + FH_WG - 1) / FH_WG, 1024);
-      k_sum_shards<<<dim3(grid), dim3(FH_WG), 0, s0->stream>>>(sp, cnt);
-    }
-    t_end(s0, FH_K_COMM);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_begin(s, FH_K_COMM); }
-  NCCL_TRY(g_rccl.GroupStart());
-  for (fh_ctx* s : c->shards) {
-    NCCL_TRY(g_rccl.AllReduce(sel(s), sel(s), count, kNcclFloat64, kNcclSum, s->comm, s->stream));
-    if (count2) NCCL_TRY(g_rccl.AllReduce(sel2(s), sel2(s), count2, kNcclFloat64, kNcclSum, s->comm, s->stream));
-  }
-  NCCL_TRY(g_rccl.GroupEnd());
-  for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_end(s, FH_K_COMM); }
-  return 0;
-}
-template <typename Sel>
-static int sum_over_shards(fh_ctx* c, Sel sel, size_t count) {
-  return sum_over_shards(c, sel, count, [](fh_ctx*) { return (double*)nullptr; }, 0);
-}
+#include "fh_host_ctx.h"
+#include "fh_host_launch.h"
 
 // ------------------------------------------------------------------------------------------------
 // library / context API
@@ -803,68 +438,6 @@ extern "C" int fh_set_prox(fh_ctx* c, int kind, double mu, double lo, double hi)
   return 0;
 }
 
-// ---- vector access --------------------------------------------------------------------------------
-static double* vec_ptr(fh_ctx* c, int which, uint64_t* len) {
-  const bool acc = c->last_accel;
-  *len = c->n;
-  // the stencil path never materialises the gradient or xhat (fh_tv.h): those ids are not addressable there
-  if (c->op == OP_STENCIL && (which == FH_VEC_G0 || which == FH_VEC_G1 || which == FH_VEC_XHAT)) return nullptr;
-  switch (which) {
-    case FH_VEC_X0: return c->X[c->xi];
-    case FH_VEC_G0: return c->G[c->gc];
-    case FH_VEC_XHAT: return c->xhat;
-    case FH_VEC_XPROX: return c->P[c->pc ^ 1];
-    case FH_VEC_X1: return acc ? c->X[c->ti] : c->P[c->pc ^ 1];
-    case FH_VEC_G1: return c->G[c->gc ^ 1];
-    case FH_VEC_BEST: return c->X[c->bi];
-    case FH_VEC_B: *len = c->m; return c->b;
-    case FH_VEC_Z: *len = c->m; return c->Z[c->zc ^ 1];
-    case FH_VEC_T0: case FH_VEC_T1: case FH_VEC_T2: case FH_VEC_T3: return c->T[which - FH_VEC_T0];
-    default: return nullptr;
-  }
-}
-
-static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
-                         double* xhat, double* xp, double* z, int sub_b);
-// z = div(x) into `z` (plain stencil pass; the scalar block is scratch afterwards)
-static int tv_image(fh_ctx* c, const double* x, double* z) { return launch_fwd_tv(c, 1, 0.0, x, nullptr, nullptr, nullptr, nullptr, z, 0); }
-// the two-launch stencil kernels read the stored image of x0: bring it up to date after z-free steps
-static int tv_refresh_zcur(fh_ctx* c) {
-  if (c->op != OP_STENCIL || !c->zcur_stale) return 0;
-  FH_TRY(tv_image(c, c->X[c->xi], c->Z[c->zc]));
-  c->zcur = c->Z[c->zc];
-  c->zcur_stale = false;
-  return 0;
-}
-
-// ---- lazily-kept stencil iterate (one-pass FISTA) ---------------------------------------------------
-static inline double* nq(fh_ctx* c, int i) { return i < 3 ? c->X[i] : c->P[i - 3]; }
-static inline double* mq(fh_ctx* c, int i) { return i < 2 ? c->Z[i] : c->ZX[0]; }
-static void lazy_pick_targets(fh_ctx* c) {
-  for (int k = 0; k < 5; ++k) if (k != c->lq1 && k != c->lq0 && k != c->lb1 && k != c->lb0) { c->lqn = k; break; }
-  for (int k = 0; k < 3; ++k) if (k != c->lz1 && k != c->lz0) { c->lzn = k; break; }
-}
-static int not_lazy(fh_ctx* c, const char* what) {
-  if (c->lazy) return fail(FH_E_STATE, "%s: this solve runs the one-pass accelerated stencil step (fh_step_accel), whose iterate is kept "
-                           "in extrapolated-on-the-fly form; call fh_init before switching kernels", what);
-  return 0;
-}
-// device pointer for fh_get_vector while the iterate is lazy: x0 / x1 / best are materialised into scratch T[2]
-static int lazy_vec(fh_ctx* c, int which, double** out) {
-  int a = -1, b = -1; double coef = 0.0;
-  switch (which) {
-    case FH_VEC_X0: case FH_VEC_X1: a = c->lq1; b = c->lq0; coef = c->lc; break;
-    case FH_VEC_BEST: a = c->lb1; b = c->lb0; coef = c->lbc; break;
-    case FH_VEC_XPROX: *out = nq(c, c->lqn); return 0;
-    default: *out = nullptr; return 0;
-  }
-  const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 4096);
-  k_extrapolate_vec<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(c->T[2], nq(c, a), nq(c, b), coef, c->n);
-  HIP_TRY(hipGetLastError());
-  *out = c->T[2];
-  return 0;
-}
-
 static inline bool m_side(int which) { return which == FH_VEC_B || which == FH_VEC_Z; }
 
 extern "C" int fh_set_vector(fh_ctx* c, int which, const double* host, uint64_t len) {
@@ -912,520 +485,6 @@ extern "C" int fh_get_vector(fh_ctx* c, int which, double* host, uint64_t len) {
   if (len != want) return fail(FH_E_ARG, "vector %d has length %llu, got %llu", which, (unsigned long long)want, (unsigned long long)len);
   HIP_TRY(hipMemcpyAsync(host, d, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return finish(c);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernel launchers
-// ------------------------------------------------------------------------------------------------
-static ProxP make_prox(fh_ctx* c, double tau) {
-  ProxP px;
-  px.kind = c->prox_kind;
-  px.thr = tau * c->mu;               // `t*self.mu`, examples/sparse_least_squares.py:44
-  px.lo = c->lo; px.hi = c->hi;
-  px.level = c->dscal + FH_NSCALARS;  // device scalar written by the level search
-  return px;
-}
-
-template <int R, int KIND>
-static void launch_fwd_rk(fh_ctx* c, const FwdP& p, unsigned grid) {
-  if (c->f32) {                                   // float32 storage: non-temporal loads only, R = 4 or 8
-    if constexpr (R == 16) k_fwd_dense<8, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-    else k_fwd_dense<R, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  }
-  else if (c->nt_loads) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_fwd_dense<R, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-}
-template <int R>
-static void launch_fwd_r(fh_ctx* c, const FwdP& p, unsigned grid, int kind) {
-  switch (kind) {
-    case PX_PLAIN:  launch_fwd_rk<R, PX_PLAIN>(c, p, grid); break;
-    case PX_SHRINK: launch_fwd_rk<R, PX_SHRINK>(c, p, grid); break;
-    case PX_NONNEG: launch_fwd_rk<R, PX_NONNEG>(c, p, grid); break;
-    case PX_LINF:   launch_fwd_rk<R, PX_LINF>(c, p, grid); break;
-    case PX_L1BALL: launch_fwd_rk<R, PX_L1BALL>(c, p, grid); break;
-    case PX_BOX:    launch_fwd_rk<R, PX_BOX>(c, p, grid); break;
-    default:        launch_fwd_rk<R, PX_IDENTITY>(c, p, grid); break;
-  }
-}
-
-// z := A * (mode 0: prox(x0 - tau g0) ; mode 1: x0) on the dense operator
-static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
-                            double* xhat, double* xp, double* z, int sub_b) {
-  // rows per pass (sweep, profiles/r01_tune_sizes.txt): 4 up to n = 32768, 8 beyond
-  // float32 storage: the x0/g0 pieces of a trip are twice as many per byte of A, so it takes 8 rows per pass from n = 32768 on
-  // to keep as many bytes of A in flight (4 rows: 4.7 TB/s at 65536^2, profiles/r02_f32_storage.txt)
-  int R = c->fwd_rows ? c->fwd_rows : (c->ld <= (c->f32 ? 16384u : 32768u) ? 4 : 8);
-  if (c->f32 && R == 16) R = 8;
-  if (mode == 0 && c->prox_kind == FH_PROX_TVBALL) return fail(FH_E_STATE, "TV-ball prox needs the stencil operator");
-  FwdP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / (c->f32 ? 4 : 2)); p.nv2 = (uint32_t)(c->nv / 2); p.n = (uint32_t)c->n; p.m = (uint32_t)c->m;
-  p.nrg = (uint32_t)(c->mp / R);
-  p.nchunks = (p.nv2 + FH_WG - 1) / FH_WG;
-  p.x0 = x0; p.g0 = g0; p.xacc0 = xacc0; p.xhat = xhat; p.xp = xp;
-  p.b = c->b; p.z = z; p.tau = tau; p.sub_b = sub_b; p.loss = c->loss_kind;
-  p.px = make_prox(c, tau);
-  const int kind = mode == 0 ? c->prox_kind : (int)PX_PLAIN;
-  unsigned grid = std::max(p.nrg, mode == 0 ? p.nchunks : 1u);
-  // measured on MI355X (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): 2 persistent workgroups per CU
-  // grid-striding over the row groups beat one workgroup per row group by 5-12 %
-  grid = (unsigned)std::min<long long>(grid, c->fwd_cap > 0 ? c->fwd_cap : 512);
-  const size_t need = ((size_t)p.nchunks * 8 + grid) * sizeof(double);
-  FH_TRY(ensure_ws(c, need));
-  p.red_n = c->ws; p.red_m = c->ws + (size_t)p.nchunks * 8;
-  p.counter = c->counters + CNT_FWD;
-  p.out = scalar_out(c);
-  t_begin(c, FH_K_FWD);
-  switch (R) {
-    case 4: launch_fwd_r<4>(c, p, grid, kind); break;
-    case 16: launch_fwd_r<16>(c, p, grid, kind); break;
-    default: launch_fwd_r<8>(c, p, grid, kind); break;
-  }
-  t_end(c, FH_K_FWD);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-template <int CPT>
-static void launch_adj_c(fh_ctx* c, const AdjP& p, unsigned grid) {
-  if (c->f32) k_adj_dense<CPT, 1, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else if (c->nt_loads) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_adj_dense<CPT, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-}
-
-struct AdjIO {
-  const double* z; const double* zacc0; int sub_b; int accel; double coef; int mode; double tau;
-  const double* x0; const double* xp; const double* xacc0; const double* xhat; double* x1; double* g1;
-  const double* g0;   // stencil path only: K-adj recomputes xhat = x0 - tau*g0
-};
-
-static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
-  AdjP p;
-  p.A = c->A; p.ld = c->ld; p.ld2 = (uint32_t)(c->ld / (c->f32 ? 4 : 2)); p.nv2 = (uint32_t)(c->nv / 2);
-  p.n = (uint32_t)c->n; p.mp = (uint32_t)c->mp; p.m = (uint32_t)c->m;
-  // auto rules from the MI355X sweeps (profiles/r01_tune_dense.txt, r01_tune_sizes.txt): about 32 slabs
-  // (more when there are few column chunks, so that >= 128 workgroups exist), slabs of 32..2048 rows, and
-  // column chunks of 2 x 16 B per lane below n = 32768, 4 x 16 B from there on (1 x for n <= 1024).
-  int CPT = c->adj_cpt;
-  if (CPT == 0) CPT = p.ld2 <= 512 ? 1 : (p.ld2 < 16384 ? 2 : 4);
-  p.ncc = (p.ld2 + FH_WG * CPT - 1) / (FH_WG * CPT);
-  uint32_t slab = (uint32_t)c->adj_slab;
-  if (slab == 0) {
-    // (float32 storage has half the column chunks per row: aim for the same ~1024 workgroups the float64 matrix gets at C2)
-    const uint64_t target_slabs = std::max<uint64_t>(32, ((c->f32 ? 1024 : 128) + p.ncc - 1) / p.ncc);
-    const uint64_t slab_min = p.ncc >= 8 ? 128 : 32;
-    uint64_t s = round_up((c->mp + target_slabs - 1) / target_slabs, 8);
-    slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s, slab_min), ADJ_MAX_SLAB);
-  }
-  p.slab_rows = slab;
-  p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
-  if (p.ncc + CNT_ADJ_CC > (uint32_t)kCounterWords) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
-  p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.loss = c->loss_kind; p.accel = io.accel; p.coef = io.coef;
-  p.mode = io.mode; p.tau = io.tau;
-  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
-  const size_t gpart_elems = (size_t)p.nslab * c->ld;
-  const size_t need = (gpart_elems + (size_t)p.ncc * 8 + p.nslab) * sizeof(double);
-  FH_TRY(ensure_ws(c, need));
-  p.gpart = c->ws; p.red_bb = c->ws + gpart_elems; p.red_f = p.red_bb + (size_t)p.ncc * 8;
-  p.cc_counter = c->counters + CNT_ADJ_CC; p.fin_counter = c->counters + CNT_ADJ_FIN;
-  p.out = scalar_out(c);
-  const unsigned grid = p.ncc * p.nslab;
-  t_begin(c, FH_K_ADJ);
-  switch (CPT) {
-    case 1: launch_adj_c<1>(c, p, grid); break;
-    case 4: launch_adj_c<4>(c, p, grid); break;
-    default: launch_adj_c<2>(c, p, grid); break;
-  }
-  t_end(c, FH_K_ADJ);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// n-side epilogue as its own launch (row-sharded runs, after the all-reduce of g1)
-static int bb_epilogue_only(fh_ctx* c, const AdjIO& io, const double* fsq_src, const double* coef_src = nullptr, const double* pack = nullptr) {
-  AdjP p;
-  memset(&p, 0, sizeof(p));
-  p.ld = c->nv; p.ld2 = (uint32_t)(c->nv / 2); p.nv2 = p.ld2; p.n = (uint32_t)c->n;
-  p.accel = io.accel; p.coef = io.coef; p.mode = 0; p.tau = io.tau;
-  p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
-  const uint32_t nchunks = (p.ld2 + FH_WG - 1) / FH_WG;
-  FH_TRY(ensure_ws(c, (size_t)nchunks * 8 * sizeof(double)));
-  p.red_bb = c->ws; p.fin_counter = c->counters + CNT_AUX; p.out = c->dscal;
-  t_begin(c, FH_K_AUX);
-  k_bb_epilogue<<<dim3(nchunks), dim3(FH_WG), 0, c->stream>>>(p, nchunks, fsq_src, coef_src, pack, c->hscal_dev);
-  c->scal_mirrored = true;         // (always the last launch before the caller's fetch_scalars)
-  t_end(c, FH_K_AUX);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// sum|x_i| and max|x_i| of an n-length device vector -> dscal[GSUM], dscal[GMAX]  (g(x0) for objective_hist[0], :143)
-static int launch_gterms(fh_ctx* c, const double* x) {
-  const unsigned grid = (unsigned)std::min<uint64_t>((c->n + FH_WG - 1) / FH_WG, 1024);
-  FH_TRY(ensure_ws(c, (size_t)grid * 2 * sizeof(double)));
-  t_begin(c, FH_K_AUX);
-  k_gterms<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(x, (uint32_t)c->n, c->ws, c->counters + CNT_AUX, scalar_out(c));
-  t_end(c, FH_K_AUX);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// clipping level alpha for FH_PROX_LINF (radius tau*mu) / FH_PROX_L1BALL (radius mu) -> dscal[FH_NSCALARS]
-static int launch_level_search(fh_ctx* c, double tau) {
-  if (c->op != OP_DENSE) return fail(FH_E_STATE, "LINF / L1BALL prox need the dense operator");
-  const double radius = c->prox_kind == FH_PROX_L1BALL ? c->mu : tau * c->mu;
-  const double* x0 = c->X[c->xi];
-  const double* g0 = c->G[c->gc];
-  double* out = c->dscal + FH_NSCALARS;
-  const uint32_t n = (uint32_t)c->n;
-  t_begin(c, FH_K_AUX);
-  if (n <= 1u * LVL_WG) k_level_search<1><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  else if (n <= 4u * LVL_WG) k_level_search<4><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  else if (n <= 16u * LVL_WG) k_level_search<16><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  else if (n <= 64u * LVL_WG) k_level_search<64><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  else k_level_search<0><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  t_end(c, FH_K_AUX);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_fwd_tv(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
-                         double* xhat, double* xp, double* z, int sub_b) {
-  (void)xhat; (void)g0;   // the stencil path materialises neither xhat nor the gradient (fh_tv.h)
-  if (mode == 0 && c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
-    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
-  const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
-  const uint32_t rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
-  const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
-  if (mode == 0) {
-    if (!c->zcur) return fail(FH_E_STATE, "fh_fwd on the stencil operator before fh_init");
-    TvStepFwdP p;
-    p.H = H; p.W = W; p.rows_wg = rows_wg;
-    p.strip_groups = ((W + TVS_FWD_OWN - 1) / TVS_FWD_OWN + 3) / 4;
-    p.x0 = x0; p.xacc0 = xacc0; p.xp = xp; p.zc = c->zcur; p.b = c->b; p.zn = z; p.tau = tau;
-    const unsigned grid = p.strip_groups * row_chunks;
-    FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-    p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
-    t_begin(c, FH_K_FWD);
-#define TV_STEP(U, NT)                                                                                           \
-  do {                                                                                                           \
-    if (c->prox_kind == FH_PROX_TVBALL) k_fwd_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
-    else k_fwd_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
-  } while (0)
-    if (c->tv_nt == 1) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
-    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
-#undef TV_STEP
-    t_end(c, FH_K_FWD);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  TvFwdP p;
-  p.H = H; p.W = W; p.rows_wg = rows_wg;
-  p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
-  (void)xp; (void)tau;
-  p.x0 = x0; p.b = c->b; p.z = z; p.sub_b = sub_b;
-  const unsigned grid = p.strip_groups * row_chunks;
-  FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
-  t_begin(c, FH_K_FWD);
-  if (c->tv_nt == 1) k_fwd_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_fwd_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  t_end(c, FH_K_FWD);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
-  const uint32_t H = (uint32_t)c->H, W = (uint32_t)c->W;
-  const uint32_t rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 128);
-  const uint32_t row_chunks = (H + rows_wg - 1) / rows_wg;
-  if (io.mode == 0) {          // FBS step: reductions only, the gradient is recomputed from z and b
-    if (!c->zcur) return fail(FH_E_STATE, "fh_adj on the stencil operator before fh_init");
-    TvStepAdjP p;
-    p.H = H; p.W = W; p.rows_wg = rows_wg;
-    p.strip_groups = ((W + TVS_ADJ_OWN - 1) / TVS_ADJ_OWN + 3) / 4;
-    p.zn = io.z; p.zacc0 = io.zacc0; p.zc = c->zcur; p.b = c->b;
-    p.accel = io.accel; p.coef = io.coef; p.tau = io.tau;
-    p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.x1 = io.x1; p.zx = c->ZX[c->zxc ^ 1];
-    const unsigned grid = p.strip_groups * row_chunks;
-    FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-    p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
-    t_begin(c, FH_K_ADJ);
-#define TV_STEP(U, NT) k_adj_tv_step<U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-    if (c->tv_nt == 1) { if (c->tv_u == 2) TV_STEP(2, 1); else if (c->tv_u == 4) TV_STEP(4, 1); else TV_STEP(8, 1); }
-    else { if (c->tv_u == 2) TV_STEP(2, 0); else if (c->tv_u == 4) TV_STEP(4, 0); else TV_STEP(8, 0); }
-#undef TV_STEP
-    t_end(c, FH_K_ADJ);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  TvAdjP p;                    // plain gradient (Lipschitz probes, fh_apply): materialises g1 = grad(z - b)
-  p.H = H; p.W = W; p.rows_wg = rows_wg;
-  p.strip_groups = ((W + TV_SW - 1) / TV_SW + 3) / 4;
-  p.z = io.z; p.b = c->b; p.sub_b = io.sub_b; p.g1 = io.g1;
-  const unsigned grid = p.strip_groups * row_chunks;
-  FH_TRY(ensure_ws(c, (size_t)grid * 8 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_ADJ_FIN; p.out = scalar_out(c);
-  t_begin(c, FH_K_ADJ);
-  if (c->tv_nt == 1) k_adj_tv<4, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else k_adj_tv<4, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  t_end(c, FH_K_ADJ);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// ---- fused one-pass iteration (fh_fused.h) ---------------------------------------------------------------
-// Shape of the one-pass launch: TEAM members x 256 lanes x PPT 16-byte pieces cover one row; lanes past the row's last
-// piece are masked (clamped loads, zero x), so any n up to 262144 fits the next shape up.  A member's piece of a row is
-// kept at 5..8 pieces per lane (20-32 KiB per workgroup per row) by choosing the team size -- fewer members means more
-// teams, i.e. fewer rows (trips of ~0.7-1.2 us) per team:
-//   n <= 4096  : 1 member  (a workgroup owns whole rows: no exchange), PPT = ceil(n/512) rounded up to 1, 2, 4, 5..8
-//   n <= 8192  : 2 members x PPT = ceil(n/1024) in 5..8, posts one row ahead
-//   n <= 16384 : 4 members x PPT = ceil(n/2048) in 5..8, posts one row ahead
-//   n <= 32768 : 8 members x PPT = ceil(n/4096) in 5..8, posts one row ahead
-//   n <= 65536 : 16 members x PPT = ceil(n/8192) in 5..8, posts two rows ahead
-//   n <= 131072: 16 members x PPT = ceil(n/8192) in 9..16, x slice in LDS, posts one row ahead (3-4 row buffers)
-//   n <= 262144: 32 members x PPT = ceil(n/16384) in 9..16, same schedule (6.1 TB/s at n = 262144: a trip with 32 members is
-//                slower, but still 1.8x the two-launch path)
-// FH_TUNE_FUSED_VARIANT bit 8 (A/B, tests): 8 members for every n <= 32768 and 8 members x 16 pieces in line at n = 65536;
-// bit 16: n in (65536, 131072] as in round 1 (16 members x 16 pieces in registers, exchange in line).
-// FusedShape = the template key of k_fused_dense (PPT, PIPE, TEAM, XLDS, NBO) for a row of n columns: a pure function of
-// (n, row stride, storage, FH_TUNE_FUSED_VARIANT, #CUs), exported as fh_fused_shape so that it can be checked without a GPU.
-struct FusedShape { int ppt, team, pipe, xlds, nbo; };
-static FusedShape fused_shape_for(uint64_t n, uint64_t ld, int f32, int variant, int ncu) {
-  const FusedShape none = {0, 0, 0, 0, 0};
-  if (ld % 2 || n == 0) return none;
-  // 16-byte pieces per row that hold data (the row stride ld may be padded): 2 columns each, 4 in float32 storage
-  const uint64_t pieces = f32 ? round_up(n, 32) / 4 : round_up(n, 16) / 2;
-  if (pieces > ld / (f32 ? 4 : 2)) return none;
-  FusedShape sh = none;
-  if (f32) {
-    // float32 storage: the same byte rule (a member's piece of a row is 5..8 pieces per lane = 20-32 KiB per workgroup per
-    // row), i.e. twice the columns per team size: n <= 8192 one member, then 2 / 4 / 8 / 16 members up to n = 131072.  A piece
-    // carries four columns, so the x and g1 slices cost twice the registers per piece: from 5 pieces on the x slice lives in
-    // LDS and 4 (5-6 pieces) or 3 (7-8 pieces) row buffers rotate, posting one row ahead -- the spill-free combinations
-    // (-Rpass-analysis=kernel-resource-usage)
-    for (int team = 1; team <= 16; team *= 2) {
-      if (pieces > (uint64_t)team * FH_WG * 8) continue;
-      int ppt = (int)((pieces + (uint64_t)team * FH_WG - 1) / ((uint64_t)team * FH_WG));
-      if (ppt == 3) ppt = 4;
-      if (team > 1 && ppt < 5) ppt = 5;          // (cannot happen: pieces > (team/2)*256*8 already means ppt >= 5)
-      const int xl = ppt >= 5 ? 1 : 0;
-      sh = {ppt, team, 1, xl, xl ? (ppt <= 6 ? 4 : 3) : 0};
-      break;
-    }
-  } else if (pieces <= (uint64_t)1 * FH_WG * 8 && !(variant & 8)) {
-    int ppt = (int)((pieces + FH_WG - 1) / FH_WG);                       // n <= 4096: a workgroup owns whole rows, 256 "teams" of one
-    if (ppt == 3) ppt = 4;
-    sh = {ppt, 1, 1, 0, 0};
-  } else if (pieces > (uint64_t)1 * FH_WG * 8 && pieces <= (uint64_t)2 * FH_WG * 8 && !(variant & 8)) {
-    sh = {(int)((pieces + 2 * FH_WG - 1) / (2 * FH_WG)), 2, 1, 0, 0};  // n in (4096, 8192]: 2 members x 5..8 pieces, 128 teams
-  } else if (pieces > (uint64_t)2 * FH_WG * 8 && pieces <= (uint64_t)4 * FH_WG * 8 && !(variant & 8)) {
-    sh = {(int)((pieces + 4 * FH_WG - 1) / (4 * FH_WG)), 4, 1, 0, 0};  // n in (8192, 16384]: 4 members x 5..8 pieces, 64 teams
-  } else if (pieces <= (uint64_t)8 * FH_WG * 8) {
-    int ppt = (int)((pieces + 8 * FH_WG - 1) / (8 * FH_WG));
-    if (ppt == 3) ppt = 4;
-    sh = {ppt, 8, 1, 0, 0};
-  } else if (pieces == (uint64_t)8 * FH_WG * 16 && (variant & 8)) {
-    sh = {16, 8, 0, 0, 0};
-  } else if (pieces <= (uint64_t)16 * FH_WG * 8) {
-    sh = {(int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG)), 16, 2, 0, 0};       // 16 members: posts run two rows ahead of the polls
-  } else if (pieces <= (uint64_t)16 * FH_WG * 16) {
-    // n in (65536, 131072]: 16 members x 9..16 pieces POSTING ONE ROW AHEAD, made possible by keeping the x slice in LDS (the
-    // registers hold 3-4 row buffers -- the largest count hipcc allocates without spilling -- and the g1 slice); measured against
-    // the round-1 in-line shape in profiles/r02_fused_wide.txt: 131072 columns 6.41 -> 4.80 ms (7.16 TB/s), 70000: 5.80 -> 2.87 ms
-    // (variant bit 16: that round-1 shape -- 16 pieces, x slice in registers, 3 row buffers, exchange in line)
-    const int ppt = (int)((pieces + 16 * FH_WG - 1) / (16 * FH_WG));
-    sh = (variant & 16) ? FusedShape{16, 16, 0, 0, 0} : FusedShape{ppt, 16, 1, 1, ppt <= 10 ? 4 : 3};
-  } else if (pieces <= (uint64_t)32 * FH_WG * 16) {
-    // n in (131072, 262144]: 32 members (a whole XCD per team, 8 teams) x 9..16 pieces, same schedule
-    const int ppt = (int)((pieces + 32 * FH_WG - 1) / (32 * FH_WG));
-    sh = {ppt, 32, 1, 1, ppt <= 10 ? 4 : 3};
-  }
-  if (!sh.ppt || ncu < sh.team || ncu % sh.team) return none;     // one workgroup per CU, whole teams only
-  return sh;
-}
-static const FusedEntry* fused_lookup(const FusedShape& sh, int f32) {
-  for (const FusedEntry& e : kFusedTable)
-    if (e.ppt == sh.ppt && e.pipe == sh.pipe && e.team == sh.team && e.xlds == sh.xlds && e.nbo == sh.nbo && e.f32 == f32) return &e;
-  return nullptr;
-}
-static FusedShape fused_shape(fh_ctx* c) {
-  if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL) return FusedShape{0, 0, 0, 0, 0};
-  return fused_shape_for(c->n, c->ld, c->f32, c->fused_variant, c->ncu);
-}
-static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
-// diagnostic / test entry: the shape chosen for n columns and whether its kernel is instantiated (no device needed)
-extern "C" int fh_fused_shape(uint64_t n, int dtype, int variant, int ncu, int* shape5, int* instantiated) {
-  if (!shape5 || !instantiated) return fail(FH_E_ARG, "null argument");
-  const int f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
-  const FusedShape sh = fused_shape_for(n, round_up(n, f32 ? 32 : 16), f32, variant, ncu);
-  shape5[0] = sh.ppt; shape5[1] = sh.pipe; shape5[2] = sh.team; shape5[3] = sh.xlds; shape5[4] = sh.nbo;
-  *instantiated = sh.ppt && fused_lookup(sh, f32) ? 1 : 0;
-  return 0;
-}
-// the one-pass launch beats K-fwd + K-adj once its fixed cost is amortised: wide rows, or at least 8 Mi elements
-// (profiles/r02_fused_crossover.txt; 32 Mi in round 1, when every launch still refilled its hand-off slots from the host)
-static bool fused_pays(fh_ctx* c) { return c->n >= 16384 || (uint64_t)c->m * c->n >= ((uint64_t)1 << 23); }
-
-// (the prox kind travels in p.px.kind: a run-time switch in the kernel's n-side prologue; FH_PROX_* == PX_* numerically.  The
-// one-pass kernels always stream A with non-temporal loads, +10 % in the dense sweeps: only NT = 1 is built.)
-// operands of one fused launch; fh_step takes them from the solver state, fh_init / fh_gradient_at pass their own
-struct FusedIO {
-  const double* x0; const double* g0; double* xhat; double* xp; double* z; double* g1;
-  int kind;     // prox kind (FH_PROX_IDENTITY with tau = 0 gives the plain pair z = A x0, g1 = A^T grad f(z))
-  int mode;     // 0 = with the n-side epilogue, 2 = g1 (+ loss) only
-  // FISTA (zero-initialised = off): x1 = xp + c*(xp - xacc0), gradient at z + c*(z - zacc0), c = coef or 0 after a restart
-  int accel = 0, restart = 0; double coef = 0.0;
-  const double* xacc0 = nullptr; const double* zacc0 = nullptr; double* x1 = nullptr; double* coef_out = nullptr;
-  double* pack = nullptr;      // row-sharded: where the launch appends its loss sums and timeout word (behind g1)
-};
-
-// after the synchronisation that follows a one-pass launch: a launch that timed out has left slots un-posted / un-armed
-static inline void fused_after(fh_ctx* c) { if (c->hscal[15] != 0.0) c->slots_sig = 0; }
-
-static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
-  const FusedShape sh = fused_shape(c);
-  if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 262144 and a scalar-separable prox)");
-  const FusedEntry* k_fused_dense_entry = fused_lookup(sh, c->f32);
-  if (!k_fused_dense_entry)
-    return fail(FH_E_STATE, "fused one-pass step: no instantiation for PPT %d, PIPE %d, TEAM %d, XLDS %d, NBO %d, F32 %d (fh_fused_instances.inc)",
-                sh.ppt, sh.pipe, sh.team, sh.xlds, sh.nbo, c->f32);
-  FusedP p;
-  p.A = c->A; p.ld = c->ld; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
-  p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
-  p.ldp = (uint32_t)(c->ld / (c->f32 ? 4 : 2));
-  p.nv2 = p.ld2 * (c->f32 ? 2u : 1u);
-  p.nteams = (uint32_t)(c->ncu / sh.team);
-  // few rows: fewer teams (at least FUSED_MIN_ROWS rows each when possible, and a multiple of 8 teams so that the members of
-  // a team stay on one XCD): a smaller grid barrier and fewer g1 partials to sum in the epilogue
-  if (c->fused_min_rows > 0) {
-    const uint64_t want = std::max<uint64_t>(8, round_up((c->mp + c->fused_min_rows - 1) / c->fused_min_rows, 8));
-    p.nteams = (uint32_t)std::min<uint64_t>(p.nteams, want);
-  }
-  p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
-  p.x0 = io.x0; p.g0 = io.g0; p.xhat = io.xhat; p.xp = io.xp;
-  p.b = c->b; p.z = io.z; p.tau = tau; p.loss = c->loss_kind; p.mode = io.mode;
-  p.px = make_prox(c, tau);
-  p.px.kind = io.kind;
-  p.accel = io.accel; p.restart = io.restart; p.coef = io.coef; p.xacc0 = io.xacc0; p.zacc0 = io.zacc0; p.x1 = io.x1; p.coef_out = io.coef_out;
-  p.pack = io.pack;
-  const unsigned grid = p.nteams * sh.team;
-  const size_t slots_elems = ((size_t)c->mp + p.nteams) * (sh.team < 8 ? 8 : sh.team);     // (32 members: four 64-byte lines per row)   // whole 64-byte lines; + one line per team for the restart dot
-  const size_t gpart_elems = (size_t)p.nteams * p.nv2 * 2;
-  FH_TRY(ensure_ws(c, (gpart_elems + (size_t)grid * 16) * sizeof(double)));
-  p.gpart = c->ws; p.red = p.gpart + gpart_elems;
-  if (2 * slots_elems * sizeof(double) > c->slotbuf_bytes) {
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->slotbuf) { HIP_TRY(hipFree(c->slotbuf)); c->slotbuf = nullptr; c->slotbuf_bytes = 0; }
-    const size_t bytes = round_up(2 * slots_elems * sizeof(double), 1 << 20);
-    HIP_TRY(hipMalloc((void**)&c->slotbuf, bytes));
-    c->slotbuf_bytes = bytes;
-    c->slots_sig = 0;
-  }
-  p.g1 = io.g1;
-  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR; p.variant = c->fused_variant;
-  p.out = scalar_out(c);
-  t_begin(c, FH_K_FUSED);
-  {
-    // signature of everything the slot layout depends on; 0 = "refill" (set after a timed-out launch, see fused_after)
-    uint64_t sig = fh_mix((uint64_t)(uintptr_t)c->slotbuf ^ fh_mix(slots_elems * 131 + (uint64_t)sh.team * 7 + p.nteams)) | 1ull;
-    if (sig != c->slots_sig) {
-      // (a team of one exchanges nothing through the slots, but its grid barrier and error word are the same counters: a launch
-      // that timed out in another shape must not leave them armed for it)
-      if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
-      HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-      c->slots_sig = sig;
-      c->slots_parity = 0;
-    }
-    p.slots = c->slotbuf + (size_t)c->slots_parity * slots_elems;
-    p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
-    c->slots_parity ^= 1;
-  }
-  k_fused_dense_entry->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  t_end(c, FH_K_FUSED);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, fused_pays()):
-// identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
-static bool cu_masked() { return getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"); }
-static bool plain_pair_fused_ok(fh_ctx* c) { return c->op == OP_DENSE && !row_sharded(c) && c->shards.empty() && fused_ppt(c) && fused_pays(c) && !cu_masked(); }
-// returns 0 and sets *ok = false when the launch reported a spin timeout (caller falls back to two launches)
-static int plain_pair_fused(fh_ctx* c, const double* x, double* z, double* g, bool* ok) {
-  const FusedIO fio = {x, x, c->xhat, c->P[c->pc ^ 1], z, g, FH_PROX_IDENTITY, 2};
-  FH_TRY(launch_fused_dense(c, 0.0, fio));
-  FH_TRY(finish(c));                          // single GPU: the scalar block (incl. the timeout word) is in mapped host memory
-  *ok = c->hscal[15] == 0.0;
-  fused_after(c);
-  return 0;
-}
-
-// ---- operator-generic wrappers ---------------------------------------------------------------------
-static int op_fwd(fh_ctx* c, int mode, double tau, const double* x0, const double* g0, const double* xacc0,
-                  double* xhat, double* xp, double* z, int sub_b) {
-  if (c->op == OP_DENSE) return launch_fwd_dense(c, mode, tau, x0, g0, xacc0, xhat, xp, z, sub_b);
-  if (c->op == OP_STENCIL) return launch_fwd_tv(c, mode, tau, x0, g0, xacc0, xhat, xp, z, sub_b);
-  return fail(FH_E_STATE, "no operator set");
-}
-
-// ---- the adjoint launch in three stages, so that a shell can run stage 1 on every shard, ONE exchange, stage 3 on every shard ----
-// stage 1, local: row-sharded contexts leave the n-side epilogue (mode 0) to adj_tail, which needs the summed g1
-static int adj_local(fh_ctx* c, const AdjIO& io_in) {
-  AdjIO io = io_in;
-  if (row_sharded(c) && c->op != OP_DENSE) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
-  if (row_sharded(c) && io.mode == 0) io.mode = 2;
-  if (c->op == OP_DENSE) return launch_adj_dense(c, io);
-  if (c->op == OP_STENCIL) return launch_adj_tv(c, io);
-  return fail(FH_E_STATE, "no operator set");
-}
-// stage 2, exchange: A_k^T r_k partials (nv doubles at g1(shard)) and the local loss sums (FH_S_FSQ_ADJ) summed over the row blocks
-template <typename Sel>
-static int adj_sum(fh_ctx* c, Sel g1) {
-  return sum_over_shards(c, g1, (size_t)c->nv, [](fh_ctx* s) { return s->dscal + FH_S_FSQ_ADJ; }, 1);
-}
-// stage 3: the n-side epilogue on the summed g1
-static int adj_tail(fh_ctx* c, const AdjIO& io) {
-  if (!row_sharded(c) || io.mode != 0) return 0;
-  return bb_epilogue_only(c, io, c->dscal + FH_S_FSQ_ADJ);
-}
-// all three on a plain context (fh_init, fh_gradient_at, fh_apply of a single context)
-static int op_adj(fh_ctx* c, const AdjIO& io) {
-  FH_TRY(adj_local(c, io));
-  double* g1 = io.g1;
-  FH_TRY(adj_sum(c, [g1](fh_ctx*) { return g1; }));
-  return adj_tail(c, io);
-}
-
-// local ||r_k||^2 (or logistic loss sum) of the forward launch summed over the row blocks, before the host's line-search test
-static int reduce_fsq_over_ranks(fh_ctx* c) {
-  return sum_over_shards(c, [](fh_ctx* s) { return s->dscal + FH_S_FSQ; }, 1);
-}
-
-static int check_ready(fh_ctx* c, bool need_b) {
-  if (!c) return fail(FH_E_ARG, "null context");
-  if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set (call fh_set_matrix / fh_generate_matrix / fh_set_stencil)");
-  if (need_b && !c->has_b) return fail(FH_E_STATE, "no loss set (call fh_set_loss_lsq)");
-  return c->shards.empty() ? use_device(c) : 0;      // (a shell selects the device shard by shard)
-}
-
-// the solver-state operands of K-adj / the n-side epilogue (fh_adj, fh_fwd_adj, fh_step on a row-sharded context)
-static AdjIO solver_adj_io(fh_ctx* c, double tau, int accel, double coef) {
-  AdjIO io;
-  io.z = c->Z[c->zc ^ 1]; io.zacc0 = c->Z[c->zc]; io.sub_b = 1; io.accel = accel ? 1 : 0; io.coef = coef;
-  io.mode = 0; io.tau = tau;
-  io.x0 = c->X[c->xi]; io.xp = c->P[c->pc ^ 1]; io.xacc0 = c->P[c->pc]; io.xhat = c->xhat;
-  io.x1 = c->X[c->ti]; io.g1 = c->G[c->gc ^ 1]; io.g0 = c->G[c->gc];
-  return io;
-}
-// K-fwd of the solver state (level search for the two sort-free prox kinds first)
-static int solver_fwd_local(fh_ctx* c, double tau, const char* who) {
-  FH_TRY(use_device(c));
-  FH_TRY(not_lazy(c, who));
-  FH_TRY(tv_refresh_zcur(c));
-  c->tvz_pending = false;
-  if (c->prox_kind == FH_PROX_LINF || c->prox_kind == FH_PROX_L1BALL) FH_TRY(launch_level_search(c, tau));
-  return op_fwd(c, 0, tau, c->X[c->xi], c->G[c->gc], c->P[c->pc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1574,116 +633,11 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   //     prologue, grid barrier, epilogue), which two short launches under one sync beat on a small matrix
   //     (profiles/r02_fused_crossover.txt: 512 x 1024 35.6 vs 34.9 us, 2048^2 46 vs 53 us, 1024 x 8192 60 vs 63 us, 4096^2 77 vs 76 us)
   int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
-  // The dense one-pass kernel needs its whole grid (one workgroup per CU the device REPORTS) co-resident.  A CU mask hides
-  // CUs from the dispatcher without changing that count: say "unsupported" up front instead of running into the bounded-spin
-  // timeout on the first launch (the timeout stays as the safety net for partition modes this check cannot see).
-  if (ppt && (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))) ppt = 0;
+  // The dense one-pass kernel needs its whole grid (one workgroup per CU the device REPORTS) co-resident: probed once per context
+  // (co_resident above); "unsupported" up front instead of a bounded-spin timeout on the first launch (the timeout stays as the
+  // safety net for CUs that disappear later).
+  if (ppt && !co_resident(c)) ppt = 0;
   *yes = c->op == OP_STENCIL ? (row_sharded(c) ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
-  return 0;
-}
-
-static int launch_fused_tv(fh_ctx* c, double tau) {
-  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
-    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
-  if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
-  TvStepFwdP p;
-  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
-  p.strip_groups = ((p.W + TVF_OWN - 1) / TVF_OWN + 3) / 4;
-  p.x0 = c->X[c->xi]; p.xacc0 = nullptr; p.xp = c->P[c->pc ^ 1]; p.zc = c->zcur; p.b = c->b; p.zn = c->Z[c->zc ^ 1];
-  p.tau = tau;
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
-  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
-  t_begin(c, FH_K_FUSED);
-#define TV_FUSED(U, NT)                                                                                            \
-  do {                                                                                                             \
-    if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_step<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
-    else k_fused_tv_step<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
-  } while (0)
-  if (c->tv_nt == 1) { if (c->tv_u == 2) TV_FUSED(2, 1); else if (c->tv_u == 4) TV_FUSED(4, 1); else TV_FUSED(8, 1); }
-  else { if (c->tv_u == 2) TV_FUSED(2, 0); else if (c->tv_u == 4) TV_FUSED(4, 0); else TV_FUSED(8, 0); }
-#undef TV_FUSED
-  t_end(c, FH_K_FUSED);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_fused_tv_accel(fh_ctx* c, double tau, double coef, int restart) {
-  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
-    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
-  TvAccelP p;
-  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.rows_wg = (uint32_t)(c->tv_rows > 0 ? c->tv_rows : 32);
-  p.strip_groups = ((p.W + TVF_OWN - 1) / TVF_OWN + 3) / 4;
-  p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn);
-  p.z1 = mq(c, c->lz1); p.z0 = mq(c, c->lz0); p.zn = mq(c, c->lzn);
-  p.b = c->b; p.tau = tau; p.cprev = c->lc; p.coef = coef; p.restart = restart;
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
-  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
-  t_begin(c, FH_K_FUSED);
-#define TV_ACCEL(U, NT)                                                                                             \
-  do {                                                                                                              \
-    if (c->prox_kind == FH_PROX_TVBALL) k_fused_tv_accel<0, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);   \
-    else k_fused_tv_accel<1, U, NT><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);                                  \
-  } while (0)
-  if (c->tv_nt == 1) { if (c->tv_u == 2) TV_ACCEL(2, 1); else if (c->tv_u == 4) TV_ACCEL(4, 1); else TV_ACCEL(8, 1); }
-  else { if (c->tv_u == 2) TV_ACCEL(2, 0); else if (c->tv_u == 4) TV_ACCEL(4, 0); else TV_ACCEL(8, 0); }
-#undef TV_ACCEL
-  t_end(c, FH_K_FUSED);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// z-free one-pass stencil step (k_tv_onepass): accel = 0 -> x0 = X[xi]; accel = 1 -> the lazily-kept (P1, P0, c) state
-static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int restart) {
-  if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
-    return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
-  TvZP p;
-  p.H = (uint32_t)c->H; p.W = (uint32_t)c->W;
-  p.strip_groups = ((p.W + TVZ_OWN - 1) / TVZ_OWN + 3) / 4;
-  if (c->tv_rows > 0) p.rows_wg = (uint32_t)c->tv_rows;
-  else {
-    // auto: as many row chunks as make the grid just FILL the resident capacity (5 workgroups per CU at 88 registers), so that all
-    // workgroups run side by side and finish together -- 2240 workgroups of 128 rows on 1280 slots ran 1.75 rounds, the last one
-    // three-quarters empty (8192^2: 128 rows 0.607 ms, 228-235 rows 0.588; profiles/r02_tune_tv.txt, r03_tune_tv.txt).  At least
-    // 32 rows per chunk (rows + 4 are read and computed), at most the image.
-    const uint32_t slots = (uint32_t)std::max(1, c->ncu) * 5u;
-    const uint32_t chunks = std::max(1u, slots / p.strip_groups);
-    p.rows_wg = std::min(p.H, std::max(32u, (p.H + chunks - 1) / chunks));
-  }
-  // rows per trip / rotating trip buffers: 2 rows, load-then-consume for the plain sweep; 4 rows x 3 rotating buffers with FISTA
-  // (two streams to read): profiles/r03_tune_tv.txt.  Every combination produces the same bits (scripts/tune_tvz.py).
-  const int tvu = c->tv_u ? c->tv_u : (accel ? 4 : 2);
-  if (accel) { p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn); p.cprev = c->lc; }
-  else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }
-  p.b = c->b; p.tau = tau; p.coef = coef; p.restart = restart;
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
-  FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
-  p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
-  t_begin(c, FH_K_FUSED);
-  // tunables -> template parameters.  Non-temporal LOADS lose 12 % here (the halo columns and rows are re-read by the neighbouring
-  // waves and workgroups through L2), so this sweep only distinguishes non-temporal (default) and plain STORES (FH_TUNE_TV_NT = 3).
-  const int nb = c->tv_pipe ? c->tv_pipe : (accel ? 3 : 1);
-  const bool nts = c->tv_nt != 3;       // stores are non-temporal unless FH_TUNE_TV_NT = 3 asks for plain ones (+2-3 %: xprox is not re-read by this launch)
-  const bool ident = c->prox_kind != FH_PROX_TVBALL;
-#define TVZ(ID, AC, U, NT, NB) k_tv_onepass<ID, AC, U, NT, NB><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
-#define TVZ_NB(AC, U, NT) do { if (nb >= 2) TVZ(0, AC, U, NT, 3); else TVZ(0, AC, U, NT, 1); } while (0)
-#define TVZ_U(AC, NT) do { if (tvu <= 2) TVZ_NB(AC, 2, NT); else if (tvu == 8) TVZ_NB(AC, 8, NT); else TVZ_NB(AC, 4, NT); } while (0)
-#define TVZ_NT(AC) do { if (nts) TVZ_U(AC, 2); else TVZ_U(AC, 0); } while (0)
-  if (ident) {        // no prox (g = None): the round-2 burst form
-    if (accel) { if (tvu == 2) TVZ(1, 1, 2, 0, 1); else if (tvu == 8) TVZ(1, 1, 8, 0, 1); else TVZ(1, 1, 4, 0, 1); }
-    else { if (tvu == 2) TVZ(1, 0, 2, 0, 1); else if (tvu == 8) TVZ(1, 0, 8, 0, 1); else TVZ(1, 0, 4, 0, 1); }
-  } else if (accel) TVZ_NT(1);
-  else TVZ_NT(0);
-#undef TVZ_NB
-#undef TVZ_NT
-#undef TVZ_U
-#undef TVZ
-  t_end(c, FH_K_FUSED);
-  HIP_TRY(hipGetLastError());
-  c->tvz_pending = true;
   return 0;
 }
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_coresident_probe": (_i32, [_ctx, _i32, C.POINTER(_i32)]),
     "fh_fused_shape": (_i32, [_u64, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_fwd_adj": (_i32, [_ctx, _dbl, _pd]),
     "fh_step": (_i32, [_ctx, _dbl, _pd]),
@@ -296,6 +297,12 @@ class HipContext:
         yes = _i32(0)
         self._call("fh_fused_supported", C.byref(yes))
         return int(yes.value)
+
+    def coresident_probe(self, workgroups):
+        """True if `workgroups` whole-CU workgroups run side by side on this device (what the dense one-pass kernel needs of #CUs)."""
+        ok = _i32(0)
+        self._call("fh_coresident_probe", int(workgroups), C.byref(ok))
+        return bool(ok.value)
 
     def step(self, tau):
         """One-pass K-fwd + K-adj (no acceleration).  Raises if the bounded spins timed out."""

@@ -182,6 +182,11 @@ int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
  * fh_fused_supported: 0 = no (n > 262144, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
  * 8 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
+/* The dense one-pass kernel needs one workgroup on every compute unit at the same time.  The library checks that once per context
+ * with a ~20 us probe launch (fh_fused_supported then reports 0 for the dense operator if CUs are hidden by a mask, a partition
+ * mode or a co-tenant); this entry runs the same probe for `workgroups` whole-CU workgroups and reports whether they all ran side
+ * by side (at most 2 ms when they cannot).                                                                                  */
+int fh_coresident_probe(fh_ctx* ctx, int workgroups, int* ok);
 /* Which variant of the one-pass kernel serves rows of n columns -- shape5 = {pieces per lane, posting distance, team members,
  * x slice in LDS, row buffers} (all 0: no one-pass kernel for this width) -- and whether that variant is compiled into the
  * library (csrc/fh_fused_instances.inc).  A pure host function: no device needed.  dtype: fh_dtype; variant: FH_TUNE_FUSED_VARIANT

@@ -243,31 +243,36 @@ def test_full_size_properties_65536():
 def test_c2_c3_full_size_first_iterations_match_oracle_loop():
     """BASELINE configs 2 (LASSO) and 3 (NNLS) at FULL size (65536^2, 32 GiB): the first FIVE iterations of the HIP solve
     against the oracle NumPy loop on ONE shared host copy of the same device-generated matrix (BASELINE.md section 4 parity
-    gate: x rtol 1e-5, scalars rtol 1e-8, identical backtrack counts).  The default path at this size is the one-pass kernel."""
+    gate: x rtol 1e-5, scalars rtol 1e-8, identical backtrack counts).  The default path at this size is the one-pass kernel.
+    A third run forces the BACKTRACKING retry path at full size (fasta/__init__.py:195-217): L and tau0 are given, and tau0 is
+    thousands of times too large, so the first iteration is re-launched with tau * 0.2 several times before it is accepted."""
     m = n = 65536
-    iters = 5
     scale = 1.0 / (np.sqrt(m) + np.sqrt(n))
-    opts = dict(max_iters=iters, tolerance=0.0, evaluate_objective=True, record_iterates=True)
+    base = dict(tolerance=0.0, evaluate_objective=True, record_iterates=True)
+    runs = (("lasso", 0.01, dict(max_iters=5)), ("nnls", 0.005, dict(max_iters=5)),          # nn_least_squares.py:49 uses 0.005
+            ("lasso_forced_backtracking", 0.01, dict(max_iters=3, L=1.0, tau0=5000.0)))
     op = fa.DenseMatrixMap.synthetic(m, n, 0, scale)
     got, rhs = {}, {}
     try:
         x_true = pr.synth_sparse_signal(n, 1)
         Ax = op(x_true)
-        for kind, sigma in (("lasso", 0.01), ("nnls", 0.005)):          # nn_least_squares.py:49 uses 0.005
+        for kind, sigma, extra in runs:
             b = Ax + sigma * np.random.RandomState(2).randn(m)
-            ls, reg = fa.LeastSquares(b), (fa.Shrink(0.02) if kind == "lasso" else fa.NonNeg())
-            solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, **opts)
+            ls, reg = fa.LeastSquares(b), (fa.NonNeg() if kind == "nnls" else fa.Shrink(0.02))
+            solver = fa.FBSolver(op, ls, reg, np.zeros(n), verbose=False, **base, **extra)
             np.random.seed(3)
             got[kind] = solver.setup().run()
-            assert solver.fused_steps == iters + got[kind].backtracks   # every launch of the loop was the one-pass kernel
+            assert solver.fused_steps == extra["max_iters"] + got[kind].backtracks   # every launch of the loop was the one-pass kernel
             rhs[kind] = b
-        A = op.host_rows(0, m)                       # 32 GiB host copy, D2H, shared by both oracle runs
+        assert got["lasso_forced_backtracking"].backtracks >= 4
+        A = op.host_rows(0, m)                       # 32 GiB host copy, D2H, shared by the oracle runs
     finally:
         op.close()
-    for kind in ("lasso", "nnls"):
-        P = pr.sparse_least_squares_from(A, rhs[kind], 0.02) if kind == "lasso" else pr.nn_least_squares_from(A, rhs[kind])
+    for kind, _, extra in runs:
+        iters = extra["max_iters"]
+        P = pr.nn_least_squares_from(A, rhs[kind]) if kind == "nnls" else pr.sparse_least_squares_from(A, rhs[kind], 0.02)
         np.random.seed(3)
-        want = fo.fasta(*P.args7(), **opts)
+        want = fo.fasta(*P.args7(), **base, **extra)
         g = got[kind]
         assert g.iteration_count == want.iteration_count == iters, kind
         assert g.backtracks == want.backtracks, kind

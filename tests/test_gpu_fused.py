@@ -344,3 +344,23 @@ def test_setup_passes_use_the_one_pass_kernel_at_large_n():
         np.testing.assert_allclose(c.get_vector(hip.VEC_T2, n), A.T @ (A @ (0.5 * x) - b), rtol=1e-10, atol=1e-13)
     finally:
         op.close()
+
+
+def test_coresidency_probe_says_yes_for_the_cus_and_no_beyond():
+    """fh_fused_supported no longer sniffs environment variables for hidden CUs: a probe launch of one whole-CU workgroup per
+    reported CU must see all of them running at once.  One workgroup MORE can never be co-resident: the probe must say so, quickly."""
+    import time
+    op = fa.DenseMatrixMap(np.ones((64, 20000)))
+    try:
+        c = op.ctx
+        assert c.fused_supported() == 1                     # probes on first use
+        ncu = 256
+        assert c.coresident_probe(ncu)
+        t0 = time.time()
+        assert not c.coresident_probe(ncu + 1)
+        assert time.time() - t0 < 1.0
+        assert c.coresident_probe(ncu) and c.coresident_probe(8)      # and the counters are left clean
+        s = _state(op, np.ones(64), 0.01, np.zeros(20000)).step(0.1)
+        assert np.isfinite(s).all()
+    finally:
+        op.close()

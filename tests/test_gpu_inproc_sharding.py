@@ -234,12 +234,14 @@ def test_refusals():
     del lib
 
 
-@pytest.mark.parametrize("workload", ["lasso", "nnls"])
-def test_config2_as_eight_row_blocks_first_iterations(workload):
-    """BASELINE config 2's matrix (65536 x 65536 float64, 32 GiB) as 8 x (8192 x 65536) row blocks on one GPU: the first three
-    iterations equal the unsharded run (scalars rtol 1e-10, iterate rtol 1e-9) and take the one-pass kernel on every block."""
+@pytest.mark.parametrize("workload,m", [("lasso", 65536), ("nnls", 65536), ("lasso", 262144)])
+def test_config2_and_config5_as_eight_row_blocks_first_iterations(workload, m):
+    """BASELINE config 2's matrix (65536 x 65536 float64, 32 GiB) as 8 x (8192 x 65536) row blocks on one GPU, and BASELINE config
+    5's matrix ITSELF (262144 x 65536, 128 GiB: it fits the 288 GB of one MI355X) as its 8 per-GPU shards of 32768 x 65536: the
+    first three iterations equal the unsharded run of the same matrix (scalars rtol 1e-10, iterate rtol 1e-9) and take the
+    one-pass kernel on every block."""
     from fasta_python_amd import synthetic
-    m = n = 65536
+    n = 65536
     scale = synthetic.lasso_scale(m, n)
     x_true = synthetic.sparse_signal(n, seed=1)
     runs = {}
@@ -258,6 +260,8 @@ def test_config2_as_eight_row_blocks_first_iterations(workload):
                 while not solver.step():
                     pass
                 res = solver.result()
+            if name == "sharded":
+                assert op.row_blocks() == [(k * (m // 8), m // 8) for k in range(8)]
             runs[name] = (res, solver.fused_steps, b)
         finally:
             op.close()

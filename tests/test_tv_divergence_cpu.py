@@ -16,12 +16,7 @@ from numpy import linalg as la
 
 from oracle import fasta_np as fo
 from oracle import problems as pr
-
-
-def first_divergence(a, b, k, rtol=1e-6):
-    """first iteration whose step size differs by more than rtol (relative), or k"""
-    d = np.abs(a[:k] - b[:k]) > rtol * np.abs(b[:k])
-    return int(np.argmax(d)) if d.any() else k
+from tests.helpers import first_divergence
 
 
 def transposed(P):
