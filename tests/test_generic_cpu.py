@@ -217,3 +217,37 @@ def test_example_command_line_runs_without_a_gpu():
 def test_generic_module_never_touches_the_device_or_the_oracle():
     src = open(os.path.join(ROOT, "fasta_python_amd", "generic.py")).read()
     assert "oracle" not in src.replace("the oracle", "") and "hip." not in src and "HipContext" not in src
+
+
+@pytest.mark.parametrize("name", ["l1ball_64x128_adaptive", "l1ball_64x128_accelerated", "l1ball_64x128_plain", "sparse_ls_64x128_adaptive"])
+def test_from_matrix_with_closures_runs_without_a_gpu_and_matches_the_reference_bitwise(name):
+    """examples/lasso.py:79 builds its operator with `LinearOperator.from_matrix(A)` and solves with Python closures (:42-47).
+    `from_matrix` returns the device-recognisable DenseMatrixMap, but it uploads LAZILY: called on host arrays it applies
+    `A @ x` / `A.T @ y` on the host (fasta/linalg.py:41), so this body runs on a GPU-less box, never creates a device context, and
+    reproduces the fixture captured from the reference bit for bit."""
+    meta, z = H.load_case(name)
+    d = H.case_data(meta, z)
+    A, b, mu = d["A"], d["b"], float(d["mu"])
+    op = LinearOperator.from_matrix(A)                                         # lasso.py:79
+    assert op.Vshape == (A.shape[1],) and op.Wshape == (A.shape[0],)
+    f = lambda z_: .5 * la.norm((z_ - b).ravel()) ** 2                         # lasso.py:42-45
+    gradf = lambda z_: z_ - b
+    if meta["kind"] == "l1ball":
+        g = lambda x: 0
+        proxg = lambda x, t: proximal.project_L1_ball(x, mu)
+    else:
+        g = lambda x: mu * la.norm(x.ravel(), 1)
+        proxg = lambda x, t: proximal.shrink(x, t * mu)
+    o = H.resolve_options(meta["options"], stopping)
+    np.random.seed(meta["solver_seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = fasta.fasta(op, f, gradf, g, proxg, np.zeros(A.shape[1]), verbose=False, **o)      # lasso.py:47
+    assert_bitwise(z, c)
+    assert op._ctx is None                                                     # no device context was ever created
+    assert np.array_equal(op(np.ones(A.shape[1])), A @ np.ones(A.shape[1])) and np.array_equal(op.H(b), A.T @ b)
+    with pytest.raises(AssertionError):
+        op(np.zeros(A.shape[1] + 1))                                           # fasta/linalg.py:58
+    with pytest.raises(AssertionError):
+        LinearOperator.from_matrix(np.zeros(3))                                # fasta/linalg.py:40
+    op.close()
