@@ -120,8 +120,13 @@ extern "C" int fh_create(int device, fh_ctx** out) {
 extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out) {
   if (!out || !dev_ids) return fail(FH_E_ARG, "fh_create_ex: null argument");
   if (ndev < 1 || ndev > FH_MAX_SHARDS) return fail(FH_E_ARG, "fh_create_ex: ndev must be in [1,%d] (got %d)", FH_MAX_SHARDS, ndev);
+  // FH_CREATE_RCCL_SHELL or'ed into dtype: build the multi-device form even for ONE device -- a shell with one shard whose exchange is
+  // the grouped ncclAllReduce on a communicator from ncclCommInitAll.  This is how a one-GPU box runs the RCCL branch of the
+  // in-process form for real (tests); it computes what a plain context computes.
+  const bool rccl_shell = (dtype & FH_CREATE_RCCL_SHELL) != 0;
+  dtype &= ~FH_CREATE_RCCL_SHELL;
   if (dtype != FH_DTYPE_F64 && dtype != FH_DTYPE_F32_STORAGE) return fail(FH_E_ARG, "fh_create_ex: unknown dtype %d", dtype);
-  if (ndev == 1) {
+  if (ndev == 1 && !rccl_shell) {
     FH_TRY(fh_create(dev_ids[0], out));
     (*out)->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
     return 0;
@@ -133,6 +138,7 @@ extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** ou
   }
   if (!distinct && !equal)
     return fail(FH_E_ARG, "fh_create_ex: device ids must be all different (one GPU per shard, RCCL) or all equal (every shard on one GPU)");
+  if (ndev == 1) equal = false;                      // (a shell of one: the RCCL form)
   fh_ctx* shell = new fh_ctx();
   for (int k = 0; k < FH_NKERNELS; ++k) shell->ev[k][0] = shell->ev[k][1] = nullptr;
   shell->device = dev_ids[0];

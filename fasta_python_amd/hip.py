@@ -24,6 +24,7 @@ K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE) = range(12)
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
+CREATE_RCCL_SHELL = 0x100          # or'ed into the dtype of fh_create_ex: the multi-device (RCCL) form even for a single device
 STORAGE = {"f64": DTYPE_F64, "f32": DTYPE_F32_STORAGE}
 
 _u64, _i32, _dbl = C.c_uint64, C.c_int, C.c_double
@@ -137,7 +138,7 @@ class HipContext:
     """One context (stream, device-resident A, vectors, workspace) on one device -- or, with `devices=[...]`, one context over
     several row blocks of A driven from this process (fh_create_ex, ndev > 1).  Not thread-safe."""
 
-    def __init__(self, device=0, storage="f64", devices=None):
+    def __init__(self, device=0, storage="f64", devices=None, rccl_shell=False):
         """storage: "f64" (default) or "f32" -- the device copy of a dense A in float32 (opt-in throughput mode; vectors,
         accumulation and scalars stay float64).
         devices: list of device ids, one per row block (in-process row sharding): all different = one GPU each, sums over RCCL;
@@ -151,7 +152,8 @@ class HipContext:
             if not devices:
                 raise ValueError("devices must name at least one device")
             ids = (_i32 * len(devices))(*devices)
-            _check(self.lib, self.lib.fh_create_ex(len(devices), ids, STORAGE[storage], C.byref(self._h)))
+            flags = CREATE_RCCL_SHELL if (rccl_shell and len(devices) == 1) else 0      # tests: the RCCL branch with one device
+            _check(self.lib, self.lib.fh_create_ex(len(devices), ids, STORAGE[storage] | flags, C.byref(self._h)))
             device = devices[0]
         elif storage == "f64":
             _check(self.lib, self.lib.fh_create(int(device), C.byref(self._h)))

@@ -118,9 +118,9 @@ LinearOperator = LinearMap      # name the reference's examples import (sparse_l
 class _DeviceMap(LinearMap):
     """A LinearMap whose operator lives in a HipContext; `fasta()` runs the fused device loop on it."""
 
-    def __init__(self, Vshape, Wshape, device, storage="f64", devices=None, lazy=False):
+    def __init__(self, Vshape, Wshape, device, storage="f64", devices=None, lazy=False, rccl_shell=False):
         self._ctx = None
-        self._ctx_args = (device, storage, devices)
+        self._ctx_args = (device, storage, devices, rccl_shell)
         self.device = device
         LinearMap.__init__(self, self._apply_fwd, self._apply_adj, Vshape, Wshape)
         if not lazy:
@@ -130,8 +130,8 @@ class _DeviceMap(LinearMap):
     def ctx(self):
         """The device context; created -- and, for a map built from a host matrix, filled -- on first use."""
         if self._ctx is None:
-            device, storage, devices = self._ctx_args
-            self._ctx = hip.HipContext(device, storage, devices=devices)
+            device, storage, devices, rccl_shell = self._ctx_args
+            self._ctx = hip.HipContext(device, storage, devices=devices, rccl_shell=rccl_shell)
             try:
                 self._on_context(self._ctx)
             except Exception:
@@ -201,7 +201,7 @@ class DenseMatrixMap(_DeviceMap):
     ranks (one process per GPU); the default is the whole matrix on one GPU.
     """
 
-    def __init__(self, A=None, device=0, tuning=None, _defer=False, storage="f64", _devices=None):
+    def __init__(self, A=None, device=0, tuning=None, _defer=False, storage="f64", _devices=None, _rccl_shell=False):
         """storage="f32" (opt-in): keep the device copy of A in float32 -- half the bytes per pass, ~2x the iterations/s on
         large matrices.  The solve is then the reference's solve on the ROUNDED matrix A.astype(float32) (all vectors and
         arithmetic stay float64), so iterates differ from the float64-matrix run by the effect of that rounding."""
@@ -211,12 +211,12 @@ class DenseMatrixMap(_DeviceMap):
         self.matrix = None                 # host copy (a reference to the caller's array, like the closures of linalg.py:41)
         self._tuning = dict(tuning or {})
         if _defer:
-            _DeviceMap.__init__(self, (0,), (0,), device, storage, _devices)
+            _DeviceMap.__init__(self, (0,), (0,), device, storage, _devices, rccl_shell=_rccl_shell)
         else:
             assert A is not None and A.ndim == 2
             self.matrix = A
             self.shape = tuple(A.shape)
-            _DeviceMap.__init__(self, (A.shape[1],), (A.shape[0],), device, storage, _devices, lazy=True)
+            _DeviceMap.__init__(self, (A.shape[1],), (A.shape[0],), device, storage, _devices, lazy=True, rccl_shell=_rccl_shell)
 
     def _on_context(self, ctx):
         """First use of the device context: tuning, then the one H2D copy of the host matrix."""
@@ -283,10 +283,13 @@ class ShardedDenseMatrixMap(DenseMatrixMap):
     kernel -- the same arithmetic on a one-GPU box.  Results differ from the unsharded operator only by the order of the
     float64 sums (~1e-15 relative)."""
 
-    def __init__(self, A=None, devices=(0, 0), tuning=None, storage="f64", _defer=False):
+    def __init__(self, A=None, devices=(0, 0), tuning=None, storage="f64", _defer=False, _rccl_shell=False):
+        """`_rccl_shell` (tests): with a single device id, still build the multi-device form -- one row block whose exchange is the
+        grouped ncclAllReduce on a communicator from ncclCommInitAll (FH_CREATE_RCCL_SHELL)."""
         devices = [int(d) for d in devices]
         self.devices = devices
-        DenseMatrixMap.__init__(self, A, device=devices[0], tuning=tuning, storage=storage, _defer=_defer, _devices=devices)
+        DenseMatrixMap.__init__(self, A, device=devices[0], tuning=tuning, storage=storage, _defer=_defer, _devices=devices,
+                                _rccl_shell=_rccl_shell)
 
     @classmethod
     def synthetic(cls, m, n, seed, scale, devices=(0, 0), tuning=None, storage="f64"):

@@ -122,6 +122,9 @@ int fh_create(int device, fh_ctx** out);
  * are those of the reference run on the ROUNDED matrix, i.e. they differ from the float64-matrix run by the rounding of A
  * (relative 6e-8 per entry; SURVEY.md section 7: <= 3e-7 on the iterates away from the chaotic regime).                  */
 enum fh_dtype { FH_DTYPE_F64 = 0, FH_DTYPE_F32_STORAGE = 1 };
+/* or'ed into dtype: build the multi-device form even when ndev == 1 -- one shard, exchange = grouped ncclAllReduce on a 1-rank
+ * communicator from ncclCommInitAll.  Same results as a plain context; lets a one-GPU box run the RCCL branch (tests).        */
+#define FH_CREATE_RCCL_SHELL 0x100
 int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out);
 /* row blocks of a context (1 for a plain one); fh_shard lends shard k -- a complete single-device context that stays owned by
  * `ctx` -- with the rows of the whole operator it holds: [row0, row0 + rows).  For diagnostics and tests (e.g. reading a

@@ -212,6 +212,50 @@ def test_synthetic_sharded_matrix_is_the_unsharded_one():
         whole.close()
 
 
+@pytest.mark.parametrize("mode", ["adaptive", "fista", "forced_backtracking"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_the_rccl_branch_of_the_in_process_form_with_one_device(mode, fused):
+    """Distinct device ids make the exchange a grouped ncclAllReduce on communicators from ncclCommInitAll.  A one-GPU box cannot have
+    two ids, but FH_CREATE_RCCL_SHELL builds that form over ONE device: dlopen of librccl, ncclCommInitAll, ncclGroupStart /
+    ncclAllReduce(n + 3) / ncclGroupEnd, the device-memory scalar block and the separate epilogue all run for real (a 1-rank sum is
+    the identity, so the solve must equal the plain context's)."""
+    np.random.seed(5)
+    P = pr.sparse_least_squares(M=96, N=160, K=6)
+    opts = dict(tolerance=1e-6, evaluate_objective=True, record_iterates=True, max_iters=300, **MODES[mode])
+    want = _oracle(P, **opts)
+    reg = fa.Shrink(P.data["mu"])
+    op = fa.ShardedDenseMatrixMap(P.data["A"], devices=[0], _rccl_shell=True)
+    whole = fa.DenseMatrixMap(P.data["A"])
+    try:
+        assert op.ctx.shard_count() == 1 and op.ctx.comm_count() == 1
+        got = _solve(op, P, reg, fused=fused, **opts)
+        ref = _solve(whole, P, reg, fused=fused, **opts)
+        comm_ms, comm_launches = op.ctx.timing_get(hip.K_COMM)
+    finally:
+        op.close()
+        whole.close()
+    _check_against(got, want, rtol_hist=1e-6, rtol_x=1e-5)
+    _check_against(got, ref, rtol_hist=1e-9, rtol_x=1e-9, atol_x=1e-13)       # (the separate epilogue kernel sums in another order)
+
+
+def test_bench_in_process_mode_on_one_gpu():
+    """`bench.py --gpus 2 --inproc --devices 0,0`: the benchmark's single-process multi-device mode, both row blocks on this GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--inproc", "--devices", "0,0", "--rows", "4096",
+                          "--cols", "8192", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["roofline"]["ranks_seen"] == 2 and out["roofline"]["comm_launches"] >= 4
+    assert "in-process" in out["config"]["parallelism"] and out["value"] > 0
+
+
 def test_refusals():
     lib = hip.load_library()
     with pytest.raises(hip.HipError, match="all different"):
