@@ -588,6 +588,9 @@ def main(argv=None):
     import fasta_python_amd as fa
     from fasta_python_amd import hip, synthetic
 
+    # device of this rank: LOCAL_RANK, folded onto the devices that exist (a node with fewer GPUs than ranks -- e.g. a rehearsal of
+    # `--gpus 2` on a one-GPU box -- puts several ranks on one device; whether RCCL accepts that is RCCL's call)
+    grp.local_rank = grp.local_rank % max(1, hip.device_count())
     fused = FUSED_OPT[args.fused]
     if args.workload == "tv":
         if grp.world != 1:

@@ -158,3 +158,36 @@ def test_random_shapes_and_modes_in_float32_storage(seed):
         warnings.simplefilter("ignore")
         want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **opts)
     _same(got, want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_modes_and_row_blocks_in_process(seed):
+    """The same random corner of the option space, solved through the single-call multi-device form with a random number of row
+    blocks on the one GPU (ShardedDenseMatrixMap, fh_create_ex ndev > 1): must equal the oracle like the unsharded solve does."""
+    rng = np.random.RandomState(2000 + seed)
+    shards = int(rng.randint(2, 9))
+    m, n = int(rng.randint(shards, 200)), int(rng.randint(1, 300))
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = rng.randn(m)
+    x0 = rng.randn(n) * (0.1 if seed % 2 else 0.0)
+    kind = ("shrink", "nonneg", "l1ball")[seed % 3]
+    adaptive, accelerate = [(True, False), (False, True), (False, False), (True, True)][seed % 4]
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=60, tolerance=1e-7,
+                evaluate_objective=bool(seed % 2), window=int(rng.randint(1, 12)), restart=bool((seed // 2) % 2),
+                fused=("auto", True, False)[seed % 3])
+    mu = 0.05
+    reg, P = {"shrink": (fa.Shrink(mu), pr.sparse_least_squares_from(A, b, mu)), "nonneg": (fa.NonNeg(), pr.nn_least_squares_from(A, b)),
+              "l1ball": (fa.L1Ball(mu), pr.l1_ball_lasso_from(A, b, mu))}[kind]
+    ls = fa.LeastSquares(b)
+    op = fa.ShardedDenseMatrixMap(A, devices=[0] * shards)
+    try:
+        np.random.seed(seed)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", **opts)
+    finally:
+        op.close()
+    oracle_opts = {k: v for k, v in opts.items() if k != "fused"}
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **oracle_opts)
+    _same(got, want)
