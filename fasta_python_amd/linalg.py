@@ -45,10 +45,13 @@ class LinearMap:
         self.Vshape, self.Wshape = tuple(Vshape), tuple(Wshape)
 
     @staticmethod
-    def from_matrix(A, device=0, storage="f64"):
+    def from_matrix(A, device=0, storage="f64", devices=None):
         """fasta/linalg.py:37-41.  Returns a DenseMatrixMap: `A @ x` / `A.T @ y` on host arrays (the reference's closures), the
-        device-resident operator once the device loop adopts it (storage="f32": opt-in float32 storage of the device copy)."""
+        device-resident operator once the device loop adopts it (storage="f32": opt-in float32 storage of the device copy;
+        devices=[...]: row blocks over several devices of this process, i.e. a ShardedDenseMatrixMap)."""
         assert A.ndim == 2
+        if devices is not None:
+            return ShardedDenseMatrixMap(A, devices=devices, storage=storage)
         return DenseMatrixMap(A, device=device, storage=storage)
 
     @staticmethod

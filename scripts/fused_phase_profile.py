@@ -7,7 +7,7 @@ from fasta_python_amd import hip
 hip.load_library(os.path.join(os.path.dirname(hip.__file__), "libfasta_hip_prof.so"))
 import fasta_python_amd as fa
 from fasta_python_amd import synthetic
-for n, m in ((4096, 4096), (8192, 8192), (16384, 8192), (65536, 8192)):
+for n, m in ((4096, 4096), (8192, 8192), (16384, 16384), (16384, 8192), (65536, 8192)):
     A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
     ctx = A.ctx
     rng = np.random.RandomState(0)
