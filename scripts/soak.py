@@ -36,6 +36,15 @@ def dense(storage):
         return A, fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n), dict(adaptive=True)
     return make
 
+def dense_blocks(m, blocks):
+    """the single-call multi-device form with all row blocks on this GPU (ShardedDenseMatrixMap, repeated device id)"""
+    def make():
+        n = 65536
+        A = fa.ShardedDenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n), devices=[0] * blocks)
+        b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
+        return A, fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n), dict(adaptive=True)
+    return make
+
 def tv(accel):
     def make():
         from fasta_python_amd.examples.tv_denoising import checkerboard
@@ -45,7 +54,16 @@ def tv(accel):
         return A, fa.LeastSquares(M / 0.1), fa.TVDualBall(), np.zeros(M.shape + (2,)), dict(adaptive=not accel, accelerate=accel)
     return make
 
-soak("LASSO 65536^2 f64", dense("f64"), 1500)
-soak("LASSO 65536^2 f32-storage", dense("f32"), 1500)
-soak("TV 8192^2 adaptive", tv(False), 1500)
-soak("TV 8192^2 FISTA", tv(True), 1500)
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "tv", "tvacc", "blocks8", "config5"]
+if "blocks8" in which:
+    soak("LASSO 65536^2 as 8 in-process row blocks", dense_blocks(65536, 8), 1500)
+if "config5" in which:
+    soak("LASSO 262144x65536 (BASELINE config 5) as 8 in-process row blocks on one GPU", dense_blocks(262144, 8), 400)
+if "dense" in which:
+    soak("LASSO 65536^2 f64", dense("f64"), 1500)
+if "f32" in which:
+    soak("LASSO 65536^2 f32-storage", dense("f32"), 1500)
+if "tv" in which:
+    soak("TV 8192^2 adaptive", tv(False), 1500)
+if "tvacc" in which:
+    soak("TV 8192^2 FISTA", tv(True), 1500)

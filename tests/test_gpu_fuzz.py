@@ -190,4 +190,5 @@ def test_random_shapes_modes_and_row_blocks_in_process(seed):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **oracle_opts)
-    _same(got, want)
+    # (histories at the north-star tolerance: 60 adaptive iterations amplify the different summation order of the row blocks to a few 1e-6)
+    _same(got, want, rtol=1e-5)
