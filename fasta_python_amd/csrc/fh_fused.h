@@ -9,7 +9,7 @@
 // sums the partials in member order, and applies r_i * (its row pieces) to its register-resident slice of g1.
 // The prox'd x slice also lives in registers, computed once per launch.
 //
-// Two schedules of the row loop (template parameter PIPE; the host picks per shape, fasta_hip.hip:fused_shape):
+// Two schedules of the row loop (template parameter PIPE; the host picks per shape, fh_host_launch.h:fused_shape_for):
 //   PIPE = D >= 1  "exchange D trips ahead": in trip t the team posts row t+D and waits for row t, which was posted D
 //             whole trips earlier, so the ~0.5 us hand-off is off the critical path; NB = 5-6 row buffers rotate
 //             (rows t..t+D held until their updates, the rest prefetching).  PPT <= 8.  D = 1 for teams of 8,
@@ -37,7 +37,7 @@
 // With acceleration (p.accel, fh_step_accel) the FISTA coefficient depends on this launch's own restart dot: every team
 // exchanges it through one extra slot line before its first row.
 // Requires n <= 262144: a row must fit TEAM*256*PPT 16-byte pieces; lanes past the row's last piece load a clamped
-// address, carry x = 0 and are masked out of every store (fasta_hip.hip:fused_shape picks the next shape up).
+// address, carry x = 0 and are masked out of every store (fh_host_launch.h:fused_shape_for picks the next shape up).
 #pragma once
 #include "fh_dense.h"
 
