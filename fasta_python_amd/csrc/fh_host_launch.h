@@ -643,6 +643,7 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   if (accel) { p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn); p.cprev = c->lc; }
   else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }
   p.b = c->b; p.tau = tau; p.coef = coef; p.restart = restart;
+  p.xcd_order = c->tv_xcd != 2;                  // FH_TUNE_TV_XCD: 0 / 1 = on, 2 = off
   const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);

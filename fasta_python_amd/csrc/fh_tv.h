@@ -47,6 +47,17 @@ __device__ __forceinline__ uint32_t tv_wrap_row(uint32_t base, int off, uint32_t
   return (uint32_t)r;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by workgroup id, and every XCD has its own L2: with the plain order, horizontally
+// adjacent strip groups -- which share their halo columns' cache lines -- always sit on DIFFERENT XCDs, so each shared line is fetched
+// from HBM twice (PMC: reads 1.15x algorithmic).  This bijection gives every XCD a contiguous range of logical ids instead
+// (workgroup b -> XCD b % 8 -> its (b / 8)-th logical id), so that neighbours in the image are neighbours in one L2.  A speed
+// heuristic only: nothing depends on where a workgroup really runs.
+__device__ __forceinline__ uint32_t tv_xcd_order(uint32_t b, uint32_t grid, int on) {
+  const uint32_t per = grid / 8u;
+  if (!on || b >= per * 8u) return b;            // the grid's last grid % 8 workgroups keep their ids
+  return (b % 8u) * per + b / 8u;
+}
+
 template <int NT>
 __device__ __forceinline__ void store_d2(d2* p, d2 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
 template <int NT>
@@ -903,6 +914,7 @@ struct TvZP {
   const double* b;                       // (H,W)
   double tau, cprev, coef;
   int restart;
+  int xcd_order;                         // 1 = logical workgroup ids dealt out XCD by XCD (tv_xcd_order)
   double* red; unsigned* counter; double* out;
 };
 
@@ -913,7 +925,8 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t sg = blockIdx.x % p.strip_groups, rc = blockIdx.x / p.strip_groups;
+  const uint32_t wg = tv_xcd_order(blockIdx.x, gridDim.x, p.xcd_order);      // logical workgroup id
+  const uint32_t sg = wg % p.strip_groups, rc = wg / p.strip_groups;
   const uint32_t i0 = rc * p.rows_wg;
   const uint32_t rows = min(p.rows_wg, p.H - i0);
   const uint32_t first = (sg * 4u + wave) * TVZ_OWN;
@@ -1072,7 +1085,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
     { const double m0 = wave_max(u0[3]), m1 = wave_max(u1[4]); if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; } }
     __syncthreads();
     if (tid == 0) {
-      double* slot = p.red + (uint64_t)blockIdx.x * 16;
+      double* slot = p.red + (uint64_t)wg * 16;              // by logical id: the finaliser's summation order does not depend on the dealing
 #pragma unroll
       for (int k = 0; k < 8; ++k) store_partial(slot + k, w[k]);
 #pragma unroll
