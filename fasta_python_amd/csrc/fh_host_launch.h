@@ -476,7 +476,10 @@ static bool run_coresident_probe(fh_ctx* c, unsigned grid) {                    
 static bool co_resident(fh_ctx* c) {
   if (c->coresident >= 0) return c->coresident != 0;
   if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) c->coresident = 0;       // known to hide CUs: no need to probe
-  else c->coresident = run_coresident_probe(c, (unsigned)std::max(1, c->ncu)) ? 1 : 0;
+  else {                                             // (a second try: a transient co-tenant must not cost this context the one-pass kernel)
+    const unsigned grid = (unsigned)std::max(1, c->ncu);
+    c->coresident = (run_coresident_probe(c, grid) || run_coresident_probe(c, grid)) ? 1 : 0;
+  }
   return c->coresident != 0;
 }
 // diagnostic: can `workgroups` whole-CU workgroups run side by side on this context's device?  (ncu: yes on a healthy device;
