@@ -3,6 +3,8 @@
 Tolerances (north-star: iterate-for-iterate rtol 1e-5): matvecs rtol 1e-12 (float64, different
 summation order than OpenBLAS); histories rtol 1e-6; iterates/solution rtol 1e-5 (+1e-9 abs).
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -143,6 +145,31 @@ def test_golden_parity_prefix_of_sensitive_runs(name, k):
     np.testing.assert_allclose(c.stepsizes[:k], z["stepsizes"][:k], rtol=1e-6)
     np.testing.assert_allclose(c.residuals[:k], z["residuals"][:k], rtol=1e-6)
     np.testing.assert_allclose(c.norm_residuals[:k], z["norm_residuals"][:k], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name,prefix", sorted(DENSE_PREFIX.items()))
+def test_sensitive_runs_first_divergence_from_the_oracle_is_measured(name, prefix, capsys):
+    """"report the first divergent iteration".  The prefix-pinned runs are continued to 300 iterations on
+    both sides and the test MEASURES where the step sizes first differ by more than 1e-6 relative: not before the pinned prefix;
+    identical backtracking decisions up to there.  (The oracle against itself with permuted rows parts at iteration 69 / 76:
+    tests/test_tv_divergence_cpu.py -- the sensitivity is the problem's.)"""
+    from tests.helpers import first_divergence
+    meta, z = H.load_case(name)
+    data = H.case_data(meta, z)
+    opts = dict(meta["options"], max_iters=300, tolerance=0.0)
+    got = G.run_hip(meta["kind"], data, opts, meta["solver_seed"])
+    P = H.oracle_problem(meta, z)
+    o = H.resolve_options(opts, fo)
+    np.random.seed(meta["solver_seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, P.x0, **o)
+    k = min(got.iteration_count, want.iteration_count)
+    first = first_divergence(got.stepsizes, want.stepsizes, k)
+    with capsys.disabled():
+        print(f"\n{name}: HIP {got.backtracks} backtracks, oracle {want.backtracks} in {k} iterations; step sizes first differ (> 1e-6 relative) at iteration {first}")
+    assert first >= prefix
+    np.testing.assert_allclose(got.residuals[:first], want.residuals[:first], rtol=1e-5)
 
 
 def test_runs_are_bitwise_repeatable():

@@ -56,3 +56,29 @@ def test_oracle_against_itself_with_a_permuted_summation_order(H, W, seed):
     fa_, fb_ = a.objectives[a.iteration_count], b.objectives[b.iteration_count]
     assert abs(fa_ - fb_) <= 1e-3 * abs(fb_)
     np.testing.assert_allclose(pr.tv_primal(M, mu, a.solution), pr.tv_primal(M, mu, np.ascontiguousarray(T(b.solution))), atol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["nnls_under_first40", "sparse_ls_unnormalised_backtracks"])
+def test_dense_sensitive_runs_against_a_row_permuted_twin(name):
+    """The same measurement for the dense fixtures that are pinned on a prefix (underdetermined NNLS with adaptive steps; the
+    unnormalised matrix that backtracks 97 times): the oracle against itself with the ROWS of A and b permuted -- the same
+    problem, every sum over the rows taken in another order.  Prints where the step sizes part."""
+    from tests import helpers as H
+    meta, z = H.load_case(name)
+    d = H.case_data(meta, z)
+    A, b = np.asarray(d["A"]), np.asarray(d["b"])
+    perm = np.random.RandomState(1).permutation(A.shape[0])
+    opts = dict(H.resolve_options(meta["options"], fo), max_iters=300, tolerance=0.0)
+    runs = []
+    for Ap, bp in ((A, b), (np.ascontiguousarray(A[perm]), b[perm])):
+        P = pr.FROM_DATA[meta["kind"]](dict(d, A=Ap, b=bp))
+        np.random.seed(meta["solver_seed"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            runs.append(fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, P.x0, **opts))
+    a, c = runs
+    k = min(a.iteration_count, c.iteration_count)
+    first = first_divergence(a.stepsizes, c.stepsizes, k)
+    print(f"\n{name}: oracle vs oracle with permuted rows: {a.backtracks} / {c.backtracks} backtracks in {k} iterations, "
+          f"step sizes first differ (> 1e-6 relative) at iteration {first}")
+    assert first >= 5
