@@ -54,8 +54,10 @@ static const int kNcclSum = 0;       // ncclSum
 
 static int rccl_load() {
   if (g_rccl.lib) return 0;
-  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  // FASTA_RCCL_LIB names another library with RCCL's entry points (a different RCCL build; the tests' multi-process stand-in)
+  const char* names[] = {getenv("FASTA_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
   for (const char* nm : names) {
+    if (!nm || !*nm) continue;
     g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
     if (g_rccl.lib) break;
   }
