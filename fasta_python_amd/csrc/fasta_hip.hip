@@ -138,22 +138,26 @@ extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** ou
   }
   if (!distinct && !equal)
     return fail(FH_E_ARG, "fh_create_ex: device ids must be all different (one GPU per shard, RCCL) or all equal (every shard on one GPU)");
-  if (ndev == 1) equal = false;                      // (a shell of one: the RCCL form)
+  // shards on ONE device always share a stream (their one-pass launches each need every CU: they must not overlap); their exchange
+  // is k_sum_shards -- unless FH_CREATE_RCCL_SHELL asks for the RCCL form anyway (needs an RCCL that accepts several ranks on one
+  // device: real RCCL does not, the tests' stand-in does)
+  const bool one_device = equal;
+  const bool use_rccl = distinct || rccl_shell;
   fh_ctx* shell = new fh_ctx();
   for (int k = 0; k < FH_NKERNELS; ++k) shell->ev[k][0] = shell->ev[k][1] = nullptr;
   shell->device = dev_ids[0];
-  shell->emulated = equal;
+  shell->emulated = !use_rccl;
   shell->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
   for (int i = 0; i < ndev; ++i) {
     fh_ctx* s = nullptr;
-    const int rc = create_one(dev_ids[i], (equal && i > 0) ? shell->shards[0]->stream : nullptr, &s);
+    const int rc = create_one(dev_ids[i], (one_device && i > 0) ? shell->shards[0]->stream : nullptr, &s);
     if (rc != 0) return create_failed(shell, rc);
-    s->owner = shell; s->emulated = equal; s->f32 = shell->f32;
+    s->owner = shell; s->emulated = shell->emulated; s->f32 = shell->f32;
     s->nranks = ndev; s->rank = i;
     shell->shards.push_back(s);
   }
   shell->ncu = shell->shards[0]->ncu;
-  if (distinct) {
+  if (use_rccl) {
     int rc = rccl_load();
     if (rc == 0) {
       std::vector<fh_nccl_comm> comms((size_t)ndev, nullptr);

@@ -152,7 +152,7 @@ class HipContext:
             if not devices:
                 raise ValueError("devices must name at least one device")
             ids = (_i32 * len(devices))(*devices)
-            flags = CREATE_RCCL_SHELL if (rccl_shell and len(devices) == 1) else 0      # tests: the RCCL branch with one device
+            flags = CREATE_RCCL_SHELL if rccl_shell else 0      # tests: the RCCL branch with one device / a repeated device id
             _check(self.lib, self.lib.fh_create_ex(len(devices), ids, STORAGE[storage] | flags, C.byref(self._h)))
             device = devices[0]
         elif storage == "f64":

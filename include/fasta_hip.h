@@ -124,8 +124,10 @@ int fh_create(int device, fh_ctx** out);
  * are those of the reference run on the ROUNDED matrix, i.e. they differ from the float64-matrix run by the rounding of A
  * (relative 6e-8 per entry; SURVEY.md section 7: <= 3e-7 on the iterates away from the chaotic regime).                  */
 enum fh_dtype { FH_DTYPE_F64 = 0, FH_DTYPE_F32_STORAGE = 1 };
-/* or'ed into dtype: build the multi-device form even when ndev == 1 -- one shard, exchange = grouped ncclAllReduce on a 1-rank
- * communicator from ncclCommInitAll.  Same results as a plain context; lets a one-GPU box run the RCCL branch (tests).        */
+/* or'ed into dtype: use the RCCL form of the multi-device context (ncclCommInitAll, grouped ncclAllReduce) where the default would
+ * not: with ndev == 1 (one shard, a 1-rank communicator: same results as a plain context), or with a repeated device id (needs an
+ * RCCL that accepts several ranks on one device -- real RCCL refuses, the tests' stand-in accepts).  Lets a one-GPU box run the
+ * RCCL branch.                                                                                                               */
 #define FH_CREATE_RCCL_SHELL 0x100
 int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** out);
 /* row blocks of a context (1 for a plain one); fh_shard lends shard k -- a complete single-device context that stays owned by

@@ -27,7 +27,13 @@ struct Shared {
   volatile unsigned phase;
   double slot[kMaxRanks][kMaxDoubles];
 };
-struct Comm { Shared* sh; int nranks, rank; char name[64]; std::vector<double> tmp; unsigned local_phase; };
+// communicators made by ncclCommInitAll live in ONE process (one host thread drives them all): their all-reduce can only run once every
+// rank's call has been issued, i.e. at ncclGroupEnd
+struct Local { int nranks; std::vector<std::vector<double>> slot; };
+struct Comm { Shared* sh; int nranks, rank; char name[64]; std::vector<double> tmp; unsigned local_phase; Local* local = nullptr; };
+struct Pending { const void* send; void* recv; size_t count; Comm* comm; hipStream_t stream; };
+static thread_local int g_depth = 0;
+static thread_local std::vector<Pending> g_pending;
 
 static void barrier(Comm* c) {
   Shared* s = c->sh;
@@ -72,20 +78,56 @@ extern "C" int ncclCommInitRank(void** comm, int nranks, ncclUniqueId id, int ra
   return ncclSuccess;
 }
 extern "C" int ncclCommInitAll(void** comms, int ndev, const int* devlist) {
-  (void)devlist;
-  if (ndev != 1) return ncclInvalidUsage;                   // (the in-process multi-device form is not what this mock is for)
-  ncclUniqueId id; ncclGetUniqueId(&id);
-  return ncclCommInitRank(&comms[0], 1, id, 0);
+  (void)devlist;                                            // (any device list, repeated ids included)
+  if (ndev < 1 || ndev > 64) return ncclInvalidUsage;
+  Local* g = new Local();
+  g->nranks = ndev; g->slot.resize((size_t)ndev);
+  for (int r = 0; r < ndev; ++r) {
+    Comm* c = new Comm();
+    c->sh = nullptr; c->nranks = ndev; c->rank = r; c->local_phase = 0; c->local = g; c->name[0] = 0;
+    comms[r] = c;
+  }
+  return ncclSuccess;
 }
 extern "C" int ncclCommDestroy(void* comm) {
   Comm* c = (Comm*)comm;
-  if (c) { munmap(c->sh, sizeof(Shared)); delete c; }
+  if (!c) return ncclSuccess;
+  if (c->local) { if (c->rank == 0) delete c->local; }      // (the library destroys its shards in reverse order: rank 0 goes last and frees the group)
+  else munmap(c->sh, sizeof(Shared));
+  delete c;
+  return ncclSuccess;
+}
+static int flush_local() {
+  // every rank of an in-process group has issued its call: D2H all, sum in rank order, H2D all
+  std::vector<Pending> ops;
+  ops.swap(g_pending);
+  while (!ops.empty()) {
+    Local* g = ops[0].comm->local;
+    const size_t count = ops[0].count;
+    std::vector<Pending> mine, rest;
+    for (const Pending& p : ops) ((p.comm->local == g && p.count == count && (int)mine.size() < g->nranks) ? mine : rest).push_back(p);
+    if ((int)mine.size() != g->nranks) return ncclInvalidUsage;           // a rank of the group is missing from this ncclGroupEnd
+    for (const Pending& p : mine) {
+      if (hipStreamSynchronize(p.stream) != hipSuccess) return ncclSystemError;
+      g->slot[(size_t)p.comm->rank].resize(count);
+      if (hipMemcpy(g->slot[(size_t)p.comm->rank].data(), p.send, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclSystemError;
+    }
+    std::vector<double> sum(count);
+    for (size_t i = 0; i < count; ++i) { double acc = g->slot[0][i]; for (int r = 1; r < g->nranks; ++r) acc += g->slot[(size_t)r][i]; sum[i] = acc; }
+    for (const Pending& p : mine)
+      if (hipMemcpy(p.recv, sum.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclSystemError;
+    ops.swap(rest);
+  }
   return ncclSuccess;
 }
 extern "C" int ncclCommCount(const void* comm, int* count) { *count = ((const Comm*)comm)->nranks; return ncclSuccess; }
 extern "C" int ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, hipStream_t stream) {
   Comm* c = (Comm*)comm;
   if (datatype != 8 || op != 0 || count > kMaxDoubles) return ncclInvalidUsage;      // ncclDouble, ncclSum
+  if (c->local) {                                           // in-process group: runs when all of its ranks have called
+    g_pending.push_back(Pending{sendbuff, recvbuff, count, c, stream});
+    return g_depth == 0 ? flush_local() : ncclSuccess;      // (outside a group only a group of one can complete)
+  }
   if (hipStreamSynchronize(stream) != hipSuccess) return ncclSystemError;
   if (hipMemcpy((void*)c->sh->slot[c->rank], sendbuff, count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ncclSystemError;
   barrier(c);
@@ -99,6 +141,6 @@ extern "C" int ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count,
   if (hipMemcpy(recvbuff, c->tmp.data(), count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return ncclSystemError;
   return ncclSuccess;
 }
-extern "C" int ncclGroupStart() { return ncclSuccess; }
-extern "C" int ncclGroupEnd() { return ncclSuccess; }
+extern "C" int ncclGroupStart() { g_depth += 1; return ncclSuccess; }
+extern "C" int ncclGroupEnd() { g_depth -= 1; return (g_depth == 0 && !g_pending.empty()) ? flush_local() : ncclSuccess; }
 extern "C" const char* ncclGetErrorString(int r) { return r == ncclSuccess ? "success" : (r == ncclInvalidUsage ? "invalid usage (mock)" : "system error (mock)"); }

@@ -125,3 +125,59 @@ def test_bench_two_real_ranks_at_the_config5_shard_shape(mock_rccl):
         assert out["roofline"]["comm_launches"] == 4                      # one exchange per iteration
     else:                                                                 # GPU sharing cost the ranks the one-pass kernel: two launches each
         assert "two launches" in out["config"]["iteration_structure"] and out["roofline"]["comm_launches"] >= 8
+
+
+INPROC_RCCL = r"""
+import json, sys, warnings
+import numpy as np
+sys.path.insert(0, {root!r})
+import fasta_python_amd as fa
+from fasta_python_amd import hip
+shards, mode, m, n = {shards}, {mode!r}, {m}, {n}
+rng = np.random.RandomState(7)
+A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+xt = np.zeros(n); xt[rng.permutation(n)[:max(1, n // 40)]] = 1
+b = A @ xt + 0.01 * rng.randn(m)
+op = fa.ShardedDenseMatrixMap(A, devices=[0] * shards, _rccl_shell=True)      # the RCCL form although the device id repeats
+assert op.ctx.shard_count() == shards and op.ctx.comm_count() == shards
+ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+opts = dict(tolerance=1e-7, evaluate_objective=True, max_iters=40, verbose=False, adaptive=(mode != "fista"), accelerate=(mode == "fista"), fused={fused})
+np.random.seed(9)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    c = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), backend="hip", **opts)
+ms, launches = op.ctx.timing_get(hip.K_COMM)
+op.close()
+k = c.iteration_count
+print("RESULT " + json.dumps(dict(iteration_count=int(k), backtracks=int(c.backtracks), residuals=c.residuals[:k].tolist(),
+                                  objectives=c.objectives[:k + 1].tolist(), solution=c.solution.tolist())))
+"""
+
+
+@pytest.mark.parametrize("shards,mode,m,n,fused", [(2, "adaptive", 96, 160, True), (8, "fista", 96, 160, True), (4, "adaptive", 300, 4096, True),
+                                                   (3, "adaptive", 200, 20000, False)])
+def test_grouped_rccl_branch_of_the_in_process_form_with_several_shards(mock_rccl, shards, mode, m, n, fused):
+    """The in-process multi-device form with DISTINCT device ids exchanges through ncclCommInitAll communicators: ncclGroupStart, one
+    ncclAllReduce per shard, ncclGroupEnd, from one host thread.  FH_CREATE_RCCL_SHELL selects that branch although the id repeats
+    (all shards on this GPU, one stream), and the stand-in -- which, unlike real RCCL, accepts several ranks on one device -- completes
+    each group at ncclGroupEnd.  So the whole grouped-exchange code path runs with 2..8 shards; only the devices are not distinct."""
+    code = INPROC_RCCL.format(root=ROOT, shards=shards, mode=mode, m=m, n=n, fused=fused)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, FASTA_RCCL_LIB=mock_rccl))
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    got = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    rng = np.random.RandomState(7)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    xt = np.zeros(n)
+    xt[rng.permutation(n)[:max(1, n // 40)]] = 1
+    b = A @ xt + 0.01 * rng.randn(m)
+    P = pr.sparse_least_squares_from(A, b, 0.02)
+    np.random.seed(9)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), tolerance=1e-7, evaluate_objective=True, max_iters=40, adaptive=(mode != "fista"), accelerate=(mode == "fista"))
+    assert got["iteration_count"] == want.iteration_count and got["backtracks"] == want.backtracks
+    k = want.iteration_count
+    np.testing.assert_allclose(got["residuals"], want.residuals[:k], rtol=1e-6)
+    np.testing.assert_allclose(got["objectives"], want.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(got["solution"], want.solution, rtol=1e-5, atol=1e-9)
