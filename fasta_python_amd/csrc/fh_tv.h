@@ -35,8 +35,9 @@ __device__ __forceinline__ d2 tv_ball(d2 y) {
 }
 
 // (base + off) mod H for the few rows a sweep steps outside its chunk (base < H, off in [-2, rows + 1], rows <= H - base): two
-// conditional corrections per side cover every H >= 1.  NOT a 64-bit `%`: hipcc expands that into ~140 scalar instructions, and
-// with two of them per image row the round-2 sweeps were bound by the CU's scalar unit (88 % busy), not by HBM.
+// conditional corrections per side cover every H >= 1.  NOT a 64-bit `%`: hipcc expands that into ~140 scalar instructions, two
+// of them per image row in the round-2 sweeps (~560 of the ~920 instructions of a two-row trip).  Removing them did not change the
+// sweep's time -- it is not issue-bound (profiles/r03_tune_tv.txt, part b) -- but there is no reason to keep them.
 __device__ __forceinline__ uint32_t tv_wrap_row(uint32_t base, int off, uint32_t H) {
   int r = (int)base + off;
   const int h = (int)H;
