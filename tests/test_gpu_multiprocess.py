@@ -27,8 +27,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def mock_rccl(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("mock_rccl") / "libmock_rccl.so")
     src = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src, "-lrt"], check=True,
-                   capture_output=True, timeout=300)
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc is needed to build the test-only RCCL stand-in")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src, "-lrt"], check=True, capture_output=True, timeout=300)
     return out
 
 
