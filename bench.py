@@ -415,8 +415,9 @@ def dense_bytes(m, n, esize=8):
             "fused": m * n * esize + (3 * m + 7 * n) * 8}
 
 
-def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False):
-    """One dense workload (LASSO or NNLS) on the resident matrix `A` (this rank's row block)."""
+def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False, plain=False):
+    """One dense workload (LASSO or NNLS) on the resident matrix `A` (this rank's row block); the three modes of the reference's
+    test_modes (examples/__init__.py:66-91): adaptive (default), accelerated (FISTA), plain (neither)."""
     import numpy as np
     import fasta_python_amd as fa
     from fasta_python_amd import synthetic
@@ -429,7 +430,7 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
     loss = fa.LeastSquares(b)
     reg = fa.Shrink(mu) if workload == "lasso" else fa.NonNeg()
-    solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not accelerate, accelerate=accelerate, verbose=False,
+    solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not (accelerate or plain), accelerate=accelerate, verbose=False,
                          max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
     np.random.seed(3)           # same Lipschitz probes on every rank
     t = timed_steps(solver, ctx, grp, warmup, steps)
@@ -696,6 +697,11 @@ def main(argv=None):
             extra["lasso_two_launch"] = sub_result(r, f"LASSO {m_total}x{n}, two launches per iteration (K-fwd + K-adj, the north-star structure)")
         r = run_dense(args, grp, A, m_total, n, "nnls", fused, args.steps, args.warmup)
         extra["nnls"] = sub_result(r, f"NNLS {m_total}x{n} (BASELINE config 3), non-negativity prox, same matrix")
+        # the reference's other two modes (examples/__init__.py:66-91 test_modes): accelerated = FISTA with restart, plain = neither
+        r = run_dense(args, grp, A, m_total, n, "lasso", fused, args.steps, args.warmup, accelerate=True)
+        extra["lasso_accelerated"] = sub_result(r, f"LASSO {m_total}x{n}, FISTA (accelerate=True, adaptive=False), one launch per iteration (fh_step_accel)")
+        r = run_dense(args, grp, A, m_total, n, "lasso", fused, args.steps, args.warmup, plain=True)
+        extra["lasso_plain"] = sub_result(r, f"LASSO {m_total}x{n}, plain FBS (adaptive=False, accelerate=False)")
         if args.gpus > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
             # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
             A.close()
