@@ -6,7 +6,8 @@ Every problem takes `backend=`:
     "hip"    device-tagged operands, the fused MI355X loop (raises without libfasta_hip.so / a GPU);
     "numpy"  the reference's closures as written there, on the generic host loop (BASELINE config 1: no GPU needed).
 
-    python -m fasta.examples.sparse_least_squares [--backend hip|numpy]
+    python -m fasta.examples.sparse_least_squares [--backend hip|numpy] [--devices 0,1,2,3]
+(--devices: sparse_least_squares only -- A row-sharded over these devices of the one process; a repeated id puts every block on that GPU)
 (without --backend the command line uses "hip" when a GPU is visible and says so when it is not).
 """
 
@@ -15,7 +16,7 @@ from abc import ABC, abstractmethod
 
 from .. import Convergence
 
-__all__ = ["ExampleProblem", "print_info", "test_modes", "cli_backend", "TOLERANCE"]
+__all__ = ["ExampleProblem", "print_info", "test_modes", "cli_backend", "cli_devices", "TOLERANCE"]
 
 TOLERANCE = 1E-5          # fasta/examples/__init__.py:16
 
@@ -70,6 +71,14 @@ def cli_backend(argv=None):
         pass
     print("no MI355X visible: running the generic NumPy host loop (--backend numpy)")
     return "numpy"
+
+
+def cli_devices(argv=None):
+    """`--devices 0,1,...` of the example command lines: row blocks of A over several devices (None when absent)."""
+    argv = sys.argv[1:] if argv is None else argv
+    if "--devices" not in argv:
+        return None
+    return [int(d) for d in argv[argv.index("--devices") + 1].split(",")]
 
 
 def print_info(solution: Convergence) -> None:

@@ -22,11 +22,13 @@ def _oracle_modes(P):
     return out
 
 
-def test_config1_sparse_least_squares_through_examples_package(capsys):
+@pytest.mark.parametrize("devices", [None, [0, 0, 0, 0]])
+def test_config1_sparse_least_squares_through_examples_package(capsys, devices):
+    """devices=[0]*4: the same example with A row-sharded over four in-process blocks (`--devices 0,0,0,0` on the command line)."""
     import fasta                                        # the drop-in name
     from fasta.examples import test_modes
     from fasta.examples.sparse_least_squares import SparseLeastSquaresProblem
-    problem, x0 = SparseLeastSquaresProblem.construct(M=512, N=1024, K=10, seed=21)
+    problem, x0 = SparseLeastSquaresProblem.construct(M=512, N=1024, K=10, seed=21, devices=devices)
     np.random.seed(21)
     P = pr.sparse_least_squares(M=512, N=1024, K=10)
     assert np.array_equal(P.data["b"], problem.b)       # same instance as the reference recipe would draw
