@@ -201,6 +201,8 @@ class FBSolver:
         if self.fused_opt is True and not self.use_fused:
             raise ValueError("fused=True needs a dense operator with n <= 262144, or a stencil operator")
         self._spec_cooldown = 0            # iterations to wait after a backtrack before speculating again
+        self._fused_backoff = 64           # iterations to stay on K-fwd / K-adj after a one-pass launch timed out (doubles per failure)
+        self._fused_retry_at = None
         self.fused_steps = 0
         self.pair_steps = 0
         self.alpha1 = 1.0                                               # :157
@@ -227,11 +229,16 @@ class FBSolver:
                     s = c.step(tau)
                 self.fused_steps += 1
                 return s, s
-            except hip.HipError as exc:                                 # bounded-spin timeout: never use it again
+            except hip.HipError as exc:                                 # bounded-spin timeout
                 # (row-sharded runs all-reduce the timeout word with g1, so every rank gets here in the same iteration
-                # and the ranks' collective sequences stay aligned)
-                warnings.warn(f"fused one-pass kernel disabled: {exc}")
+                # and the ranks' collective sequences stay aligned.)  The usual cause is a co-tenant on the GPU -- the launch
+                # needs every CU at once -- which may be gone later: fall back to K-fwd / K-adj now and try the one-pass
+                # kernel again after `_fused_backoff` iterations, doubling the wait each time it fails (a failed try costs
+                # the ~0.4 s of the bounded spins).
+                warnings.warn(f"fused one-pass kernel disabled for the next {self._fused_backoff} iterations: {exc}")
                 self.use_fused = False
+                self._fused_retry_at = self.i + self._fused_backoff
+                self._fused_backoff *= 2
         return c.fwd(tau), None
 
     # ------------------------------------------------------------------------------------------
@@ -242,6 +249,8 @@ class FBSolver:
         tau = self.tau_next                                             # :178
 
         fval = self._fval
+        if self._fused_retry_at is not None and i >= self._fused_retry_at:      # (every rank holds the same counters: same decision)
+            self.use_fused, self._fused_retry_at = True, None
         speculate = self.fused_always or self._spec_cooldown == 0
         s, a = self._forward(tau, speculate)                            # :181-188  (K-fwd, or K-fwd + K-adj in one pass)
         if not speculate:

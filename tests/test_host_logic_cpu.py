@@ -117,3 +117,42 @@ def test_linear_map_algebra_on_the_host():
     assert L.Vshape == L.Wshape == (5,)
     with pytest.raises(AssertionError):
         A(np.zeros(5))
+
+
+def test_one_pass_kernel_is_retried_with_backoff_after_a_timeout():
+    """A hand-off timeout (a co-tenant on the GPU: the launch needs every CU at once) makes the driver fall back to K-fwd / K-adj --
+    but not for the rest of the solve: it tries the one-pass kernel again after `_fused_backoff` iterations and doubles the wait
+    each time the launch fails again.  The iterates do not depend on which kernels ran."""
+    from fasta_python_amd import hip
+    meta, z = H.load_case("sparse_ls_64x128_adaptive")
+    d = H.case_data(meta, z)
+    runs = {}
+    for fail_at in ((), (2, 6)):                          # indices of the one-pass launches that time out
+        op = FakeDenseMap(d["A"], fused_kind=1)
+        real_step, launches = op.ctx.step, []
+
+        def step(tau, real_step=real_step, launches=launches, fail_at=fail_at):
+            launches.append(len(launches))
+            out = real_step(tau)                          # (the collectives of a timed-out launch still complete)
+            if launches[-1] in fail_at:
+                raise hip.HipError("fused one-pass kernel: team hand-off timed out (injected)")
+            return out
+        op.ctx.step = step
+        ls, reg = fa.LeastSquares(d["b"]), fa.Shrink(float(d["mu"]))
+        np.random.seed(meta["solver_seed"])
+        solver = fa.FBSolver(op, ls, reg, np.zeros(d["A"].shape[1]), verbose=False, max_iters=40, tolerance=0.0).setup()
+        solver._fused_backoff = 3
+        disabled = []
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            while not solver.step():
+                disabled.append(not solver.use_fused)
+        runs[fail_at] = (solver.result(), disabled, len(launches), op.ctx.calls["fwd"])
+    (ref, dis0, n0, fwd0), (got, dis1, n1, fwd1) = runs[()], runs[(2, 6)]
+    assert not any(dis0) and fwd0 == 0
+    # launch 2 = iteration 2 fails: iterations 2, 3, 4 run two launches, iteration 5 retries (launch 3), ... launch 6 fails -> 6 more
+    assert dis1[2] and dis1[3] and dis1[4] and not dis1[5]
+    assert sum(dis1) == 3 + 6 and fwd1 >= 9 and n1 < n0
+    assert got.iteration_count == ref.iteration_count == 40 and got.backtracks == ref.backtracks
+    np.testing.assert_allclose(got.residuals, ref.residuals, rtol=1e-12)
+    np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
