@@ -241,6 +241,9 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_PIPE:
       if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_PIPE must be 0 (auto), 1 (load a trip, consume it) or 3 (three rotating trip buffers; 2 is taken as 3)");
       c->tv_pipe = (int)value; return 0;
+    case FH_TUNE_TV_LDS_PAD:
+      if (value < 0 || value > 65536) return fail(FH_E_ARG, "TV_LDS_PAD must be in [0, 65536] bytes");
+      c->tv_lds_pad = (int)value; return 0;
     case FH_TUNE_TV_XCD:
       if (value < 0 || value > 2) return fail(FH_E_ARG, "TV_XCD must be 0 (auto), 1 (on) or 2 (off)");
       c->tv_xcd = (int)value; return 0;

@@ -156,6 +156,7 @@ struct fh_ctx {
   int tv_u = 0;              // 0 = auto: 8 for the kernels that stream z, 2 / 4 for the z-free one-pass sweeps (profiles/r02_tune_tv.txt)
   int tv_rows = 0;           // 0 = auto (32 fwd / 128 adj)
   int tv_nt = 0;
+  int tv_lds_pad = 0;        // FH_TUNE_TV_LDS_PAD
   int tv_xcd = 0;            // FH_TUNE_TV_XCD: workgroup ids of the one-pass sweep dealt out XCD by XCD (0 / 1 = on, 2 = off)
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt

@@ -656,7 +656,8 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   const int nb = c->tv_pipe ? c->tv_pipe : (accel ? 3 : 1);
   const bool nts = c->tv_nt != 3;       // stores are non-temporal unless FH_TUNE_TV_NT = 3 asks for plain ones (+2-3 %: xprox is not re-read by this launch)
   const bool ident = c->prox_kind != FH_PROX_TVBALL;
-#define TVZ(ID, AC, U, NT, NB) k_tv_onepass<ID, AC, U, NT, NB><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p)
+  // FH_TUNE_TV_LDS_PAD: bytes of (unused) dynamic LDS per workgroup -- an occupancy limiter for experiments (fewer, fatter streams)
+#define TVZ(ID, AC, U, NT, NB) k_tv_onepass<ID, AC, U, NT, NB><<<dim3(grid), dim3(FH_WG), (size_t)c->tv_lds_pad, c->stream>>>(p)
 #define TVZ_NB(AC, U, NT) do { if (nb >= 2) TVZ(0, AC, U, NT, 3); else TVZ(0, AC, U, NT, 1); } while (0)
 #define TVZ_U(AC, NT) do { if (tvu <= 2) TVZ_NB(AC, 2, NT); else if (tvu == 8) TVZ_NB(AC, 8, NT); else TVZ_NB(AC, 4, NT); } while (0)
 #define TVZ_NT(AC) do { if (nts) TVZ_U(AC, 2); else TVZ_U(AC, 0); } while (0)

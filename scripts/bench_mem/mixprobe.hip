@@ -53,27 +53,38 @@ __global__ __launch_bounds__(256) void k_copy(const d2* __restrict__ s, d2* __re
 }
 
 // tvmix: per tile of U*256 pixels: x (16 B/pixel), b (8 B/pixel, read as d2 by half the lanes' worth of accesses), xp (16 B/pixel)
-template <int U, int NB, int NTL, int NTS>
+// B8 = 1: b is read as ONE 8-byte value per lane and pixel (U loads of 512 B per wave), the way the sweep reads it, instead of U/2
+// 16-byte loads; OWN < 64: only the first OWN lanes of each wave store (the sweep's 60 of 64)
+template <int U, int NB, int NTL, int NTS, int B8 = 0, int OWN = 64>
 __global__ __launch_bounds__(256) void k_tvmix(const d2* __restrict__ x, const d2* __restrict__ b, d2* __restrict__ xp, uint64_t npix) {
   static_assert(U % 2 == 0, "U even");
   const uint64_t tile = (uint64_t)U * 256;
   const uint64_t ntiles = npix / tile;
-  struct Buf { d2 x[U]; d2 b[U / 2]; };
+  struct Buf { d2 x[U]; d2 b[U / 2]; double b8[B8 ? U : 1]; };
   Buf b0, b1, b2;
   auto load = [&](Buf& buf, uint64_t t) {
     const uint64_t tt = t < ntiles ? t : ntiles - 1;
     const uint64_t base = tt * tile + threadIdx.x, bbase = tt * (tile / 2) + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < U; ++j) buf.x[j] = ld<NTL>(x + base + (uint64_t)j * 256);
+    if (B8) {
 #pragma unroll
-    for (int j = 0; j < U / 2; ++j) buf.b[j] = ld<NTL>(b + bbase + (uint64_t)j * 256);
+      for (int j = 0; j < U; ++j) buf.b8[j] = reinterpret_cast<const double*>(b)[base + (uint64_t)j * 256];
+    } else {
+#pragma unroll
+      for (int j = 0; j < U / 2; ++j) buf.b[j] = ld<NTL>(b + bbase + (uint64_t)j * 256);
+    }
     asm volatile("" ::: "memory");
   };
   auto store = [&](const Buf& buf, uint64_t t) {
-    if (t < ntiles) {
+    if (t < ntiles && (threadIdx.x & 63) < OWN) {
       const uint64_t base = t * tile + threadIdx.x;
 #pragma unroll
-      for (int j = 0; j < U; ++j) { d2 v = buf.x[j]; v.x += buf.b[j / 2].x; v.y += buf.b[j / 2].y; st<NTS>(xp + base + (uint64_t)j * 256, v); }
+      for (int j = 0; j < U; ++j) {
+        d2 v = buf.x[j];
+        if (B8) v.x += buf.b8[j]; else { v.x += buf.b[j / 2].x; v.y += buf.b[j / 2].y; }
+        st<NTS>(xp + base + (uint64_t)j * 256, v);
+      }
     }
     asm volatile("" ::: "memory");
   };
@@ -232,6 +243,12 @@ int main() {
 #define MIX(U, NB, NTL, NTS, G) do { snprintf(name, sizeof name, "tvmix U=%-2d NB=%d ld=%s st=%s grid=%d", U, NB, NTL ? "nt" : "pl", NTS ? "nt" : "pl", G); \
     if (run(name, 40.0 * P, [&] { k_tvmix<U, NB, NTL, NTS><<<G, 256>>>(x, b, xp, P); })) return 1; } while (0)
   {
+    printf("=== tile-shaped tvmix, one change at a time towards the sweep's accesses (grid 256 and 2048)\n");
+#define MIXV(U, B8, OWN, G) do { snprintf(name, sizeof name, "tvmix U=%d NB=3 ld=nt st=nt b=%s stores=%d/64 lanes grid=%d", U, B8 ? "8B/lane" : "16B", OWN, G); \
+    if (run(name, (24.0 + 16.0 * OWN / 64.0) * P, [&] { k_tvmix<U, 3, 1, 1, B8, OWN><<<G, 256>>>(x, b, xp, P); })) return 1; } while (0)
+    for (int G : {256, 2048}) { MIXV(4, 0, 64, G); MIXV(4, 1, 64, G); MIXV(4, 0, 60, G); MIXV(4, 1, 60, G); MIXV(2, 0, 64, G); MIXV(2, 1, 64, G); MIXV(2, 1, 60, G); }
+  }
+  {
     const uint32_t H = 8192, W = 8192;
     printf("=== TV sweep access shape, no arithmetic (40*P algorithmic bytes); pitch = row stride in pixels\n");
     d2 *xq, *xpq; double* bq;                       // padded-pitch copies (pitch up to W + 256)
@@ -244,12 +261,7 @@ int main() {
     if (PANEL && (uint64_t)sgs * NW * OWN > W + 256) { printf("skipped: panels of %d pixels overrun the arrays\n", NW * OWN); break; } \
     snprintf(name, sizeof name, "strip own=%d U=%d NB=%d st=%s waves=%d rows=%d layout=%s grid=%u", OWN, U, NB, NTS ? "nt" : "pl", NW, ROWS, PANEL ? "panels" : "rows", g); \
     if (run(name, 40.0 * P, [&] { k_strip<OWN, U, NB, NTS, 0, NW, PANEL><<<g, 64 * NW>>>(xq, bq, xpq, H, W, W, ROWS, sgs); })) return 1; } while (0)
-    // W = 8192 is not a multiple of 240: the last panel is partial (columns past W are masked), the arrays are over-allocated (H x (W + 256))
-    PSTRIP(60, 2, 1, 1, 4, 128, 0); PSTRIP(60, 2, 1, 1, 4, 128, 1); PSTRIP(60, 2, 3, 1, 4, 128, 0); PSTRIP(60, 2, 3, 1, 4, 128, 1);
-    PSTRIP(60, 4, 3, 1, 4, 128, 1); PSTRIP(60, 2, 1, 1, 4, 228, 0); PSTRIP(60, 2, 1, 1, 4, 228, 1); PSTRIP(60, 2, 3, 1, 4, 228, 1); PSTRIP(60, 4, 3, 1, 4, 228, 1);
-    PSTRIP(60, 2, 3, 1, 4, 64, 1); PSTRIP(60, 2, 3, 1, 4, 32, 1); PSTRIP(60, 2, 3, 1, 4, 512, 1); PSTRIP(60, 2, 3, 0, 4, 128, 1);
-    PSTRIP(60, 2, 3, 1, 2, 128, 1); PSTRIP(60, 2, 1, 1, 2, 128, 1); PSTRIP(64, 2, 3, 1, 4, 128, 1); PSTRIP(64, 2, 1, 1, 4, 128, 1);
-    // (8 waves per panel = 480-pixel panels need 18 x 480 = 8640 columns of storage: beyond the H x (W + 256) arrays allocated here -- not run)
+    PSTRIP(60, 2, 3, 1, 4, 128, 0); PSTRIP(64, 2, 3, 1, 4, 128, 0); PSTRIP(60, 2, 3, 1, 4, 32, 0);
     CK(hipFree(xq)); CK(hipFree(xpq)); CK(hipFree(bq));
   }
   return 0;

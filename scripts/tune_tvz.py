@@ -19,6 +19,7 @@ def ints(i, default):
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 nts, pipes, us, rowss = ints(2, (3, 2)), ints(3, (1, 3)), ints(4, (2, 4, 8)), ints(5, (128, 0))       # TV_NT 3 = plain stores, 2 = nt stores; rows 0 = auto
+pads = ints(7, (0,))                                                                                # TV_LDS_PAD bytes (occupancy limiter)
 xcds = ints(6, (2,))                                                                                # TV_XCD 2 = plain blockIdx order, 1 = XCD by XCD
 P = side * side
 rng = np.random.RandomState(0)
@@ -59,8 +60,9 @@ for key, v in ((hip.TUNE_TV_NT, 3), (hip.TUNE_TV_PIPE, 1), (hip.TUNE_TV_U, 2), (
     ctx.set_tuning(key, v)
 ref = signature()
 NT = {0: "default", 1: "nt st (1)", 2: "nt st", 3: "plain st"}
-for nt, pipe, u, rows, xcd in itertools.product(nts, pipes, us, rowss, xcds):
+for nt, pipe, u, rows, xcd, pad in itertools.product(nts, pipes, us, rowss, xcds, pads):
     ctx.set_tuning(hip.TUNE_TV_XCD, xcd)
+    ctx.set_tuning(hip.TUNE_TV_LDS_PAD, pad)
     ctx.set_tuning(hip.TUNE_TV_NT, nt)
     ctx.set_tuning(hip.TUNE_TV_PIPE, pipe)
     ctx.set_tuning(hip.TUNE_TV_U, u)
@@ -80,6 +82,6 @@ for nt, pipe, u, rows, xcd in itertools.product(nts, pipes, us, rowss, xcds):
         ctx.step_accel(0.1, 0.3, True)
         ctx.commit(False)
     ta = timed(acc)
-    print(f"{NT[nt]:9s} pipe={pipe} U={u} rows={rows:3d} xcd={xcd}  plain {t:6.4f} ms {40 * P / t / 1e6:6.0f} GB/s | FISTA {ta:6.4f} ms {56 * P / ta / 1e6:6.0f} GB/s"
+    print(f"{NT[nt]:9s} pipe={pipe} U={u} rows={rows:3d} xcd={xcd} pad={pad:5d}  plain {t:6.4f} ms {40 * P / t / 1e6:6.0f} GB/s | FISTA {ta:6.4f} ms {56 * P / ta / 1e6:6.0f} GB/s"
           f" | xprox {'same bits' if same_x else 'DIFFERS'}, scalars {'same bits' if exact else ('rtol 1e-12' if close else 'DIFFER')}", flush=True)
 A.close()
