@@ -9,8 +9,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-import fasta_python_amd as fa
 from fasta_python_amd import hip
+if os.environ.get("FASTA_LIB"):                    # an experimental build of the library (A/B on one box)
+    hip.load_library(os.environ["FASTA_LIB"])
+import fasta_python_amd as fa
 
 
 def ints(i, default):
