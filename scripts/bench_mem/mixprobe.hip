@@ -262,6 +262,9 @@ int main() {
     snprintf(name, sizeof name, "strip own=%d U=%d NB=%d st=%s waves=%d rows=%d layout=%s grid=%u", OWN, U, NB, NTS ? "nt" : "pl", NW, ROWS, PANEL ? "panels" : "rows", g); \
     if (run(name, 40.0 * P, [&] { k_strip<OWN, U, NB, NTS, 0, NW, PANEL><<<g, 64 * NW>>>(xq, bq, xpq, H, W, W, ROWS, sgs); })) return 1; } while (0)
     PSTRIP(60, 2, 3, 1, 4, 128, 0); PSTRIP(64, 2, 3, 1, 4, 128, 0); PSTRIP(60, 2, 3, 1, 4, 32, 0);
+    // aligned 64-lane strips in PANELS of 256 pixels (32 panels x 4 KiB rows: every workgroup streams one contiguous region, no halo at all)
+    PSTRIP(64, 2, 3, 1, 4, 128, 1); PSTRIP(64, 4, 3, 1, 4, 128, 1); PSTRIP(64, 4, 3, 1, 4, 256, 1); PSTRIP(64, 4, 3, 1, 4, 32, 1); PSTRIP(64, 4, 3, 1, 4, 1024, 1);
+    PSTRIP(64, 2, 1, 1, 4, 128, 1); PSTRIP(64, 4, 3, 0, 4, 128, 1);
     CK(hipFree(xq)); CK(hipFree(xpq)); CK(hipFree(bq));
   }
   return 0;
