@@ -241,6 +241,12 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_PIPE:
       if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_PIPE must be 0 (auto), 1 (load a trip, consume it) or 3 (three rotating trip buffers; 2 is taken as 3)");
       c->tv_pipe = (int)value; return 0;
+    case FH_TUNE_TV_SLOTS:
+      if (value < 0 || value > 8) return fail(FH_E_ARG, "TV_SLOTS must be in [0, 8] workgroups per CU (0 = one workgroup per chunk)");
+      c->tv_slots = (int)value; return 0;
+    case FH_TUNE_TV_RING:
+      if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_RING must be 0 (auto), 1 (register-staged trips), 2 or 3 (LDS-DMA ring slots per wave)");
+      c->tv_ring = (int)value; return 0;
     case FH_TUNE_TV_LDS_PAD:
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "TV_LDS_PAD must be in [0, 65536] bytes");
       c->tv_lds_pad = (int)value; return 0;

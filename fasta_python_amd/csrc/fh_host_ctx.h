@@ -158,6 +158,8 @@ struct fh_ctx {
   int tv_nt = 0;
   int tv_lds_pad = 0;        // FH_TUNE_TV_LDS_PAD
   int tv_xcd = 0;            // FH_TUNE_TV_XCD: workgroup ids of the one-pass sweep dealt out XCD by XCD (0 / 1 = on, 2 = off)
+  int tv_slots = 0;          // FH_TUNE_TV_SLOTS: persistent one-pass sweep, workgroups per CU (0 = one workgroup per chunk)
+  int tv_ring = 0;           // FH_TUNE_TV_RING: LDS-DMA trip ring of the one-pass sweep (0 = auto, 1 = off, 2 / 3 = slots per wave)
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
   int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)

@@ -647,7 +647,11 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }
   p.b = c->b; p.tau = tau; p.coef = coef; p.restart = restart;
   p.xcd_order = c->tv_xcd != 2;                  // FH_TUNE_TV_XCD: 0 / 1 = on, 2 = off
-  const unsigned grid = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  p.nchunks = p.strip_groups * ((p.H + p.rows_wg - 1) / p.rows_wg);
+  // FH_TUNE_TV_SLOTS: persistent form -- at most that many workgroups per CU, each walking the chunk ids with the grid as its stride
+  // (0 = one workgroup per chunk, the round-3 form)
+  unsigned grid = p.nchunks;
+  if (c->tv_slots > 0) grid = std::min(grid, (unsigned)std::max(1, c->ncu) * (unsigned)c->tv_slots);
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
@@ -661,11 +665,20 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
 #define TVZ_NB(AC, U, NT) do { if (nb >= 2) TVZ(0, AC, U, NT, 3); else TVZ(0, AC, U, NT, 1); } while (0)
 #define TVZ_U(AC, NT) do { if (tvu <= 2) TVZ_NB(AC, 2, NT); else if (tvu == 8) TVZ_NB(AC, 8, NT); else TVZ_NB(AC, 4, NT); } while (0)
 #define TVZ_NT(AC) do { if (nts) TVZ_U(AC, 2); else TVZ_U(AC, 0); } while (0)
+  // FH_TUNE_TV_RING: LDS-DMA trip ring (2-row trips; the b pieces need 16-byte aligned rows, i.e. an even width)
+  const int ring = (c->tv_ring >= 2 && p.W % 2 == 0 && !ident) ? c->tv_ring : 0;
+#define TVZ_RING(AC, R) do { if (nts) k_tv_onepass<0, AC, 2, 2, 1, R><<<dim3(grid), dim3(FH_WG), (size_t)c->tv_lds_pad, c->stream>>>(p); \
+                             else k_tv_onepass<0, AC, 2, 0, 1, R><<<dim3(grid), dim3(FH_WG), (size_t)c->tv_lds_pad, c->stream>>>(p); } while (0)
+  if (ring) {
+    if (accel) { if (ring == 2) TVZ_RING(1, 2); else TVZ_RING(1, 3); }
+    else { if (ring == 2) TVZ_RING(0, 2); else TVZ_RING(0, 3); }
+  } else
   if (ident) {        // no prox (g = None): the round-2 burst form
     if (accel) { if (tvu == 2) TVZ(1, 1, 2, 0, 1); else if (tvu == 8) TVZ(1, 1, 8, 0, 1); else TVZ(1, 1, 4, 0, 1); }
     else { if (tvu == 2) TVZ(1, 0, 2, 0, 1); else if (tvu == 8) TVZ(1, 0, 8, 0, 1); else TVZ(1, 0, 4, 0, 1); }
   } else if (accel) TVZ_NT(1);
   else TVZ_NT(0);
+#undef TVZ_RING
 #undef TVZ_NB
 #undef TVZ_NT
 #undef TVZ_U

@@ -908,6 +908,19 @@ __device__ __forceinline__ double tvz_from_right(double v) {      // == __shfl_d
   return __hiloint2double(hi, lo);
 }
 
+
+// ---- LDS-DMA helpers for the RING form of k_tv_onepass (round 4) ----------------------------------------------------------------
+// One `global_load_lds_dwordx4`: every lane names its own 16-byte SOURCE, the destination is wave-uniform: M0 base + lane * 16.
+// M0 is compiler-reserved, so it is written and restored inside the statement that reads it.  Counted in vmcnt like any load.
+__device__ __forceinline__ void tv_glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void tv_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((address_space(3))) const d2* tv_lds_d2;
+typedef __attribute__((address_space(3))) const double* tv_lds_f64;
+
 struct TvZP {
   uint32_t H, W, strip_groups, rows_wg;
   const double* p1; const double* p0;   // (H,W,2): x0 = p1 (ACCEL: p1 + cprev*(p1 - p0), the last two prox outputs)
@@ -916,17 +929,35 @@ struct TvZP {
   double tau, cprev, coef;
   int restart;
   int xcd_order;                         // 1 = logical workgroup ids dealt out XCD by XCD (tv_xcd_order)
+  uint32_t nchunks;                      // strip_groups * row bands; a smaller grid walks the chunk ids with stride gridDim.x
   double* red; unsigned* counter; double* out;
 };
 
 // NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (FH_TUNE_TV_NT: 0 none, 1 both, 2 stores only, 3 loads only)
-template <int IDENT, int ACCEL, int TV_U, int NT, int NB = 1>
+// RING > 0 (round 4): the trips are not loaded into registers but prefetched by LDS-DMA into a ring of RING trip slots PER WAVE
+// (x1 rows 1 KiB each | x0 rows likewise with ACCEL | b rows 512 B each, two rows per DMA instruction).  The wave that issues a
+// DMA is the wave that reads the slot, so its own counted vmcnt is the only ordering needed -- no barrier, no flags; the loads in
+// flight cost no registers, so RING - 1 trips stay in flight behind the one being consumed at the register budget of the burst
+// form (which has none in flight while it computes).  Needs an even W (16-byte aligned b pieces) and TV_U = 2.
+template <int IDENT, int ACCEL, int TV_U, int NT, int NB = 1, int RING = 0>
 __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
   constexpr int NTL = NT & 1, NTS = (NT >> 1) & 1;
   __shared__ __attribute__((aligned(16))) double s_scr[4 * 8];
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t wg = tv_xcd_order(blockIdx.x, gridDim.x, p.xcd_order);      // logical workgroup id
+  const uint32_t w0 = tv_xcd_order(blockIdx.x, gridDim.x, p.xcd_order);      // logical workgroup id
+  const bool lag = ACCEL && p.cprev != 0.0;                       // uniform: the previous step extrapolated
+  const double rtau = 1.0 / p.tau;
+  double v[5] = {0, 0, 0, 0, 0};                                  // dxg0, dx2, xh2, g02, restart dot
+  double u0[4] = {0, 0, 0, 0};                                    // c = 0     : dxdg, dg2, gsum, gmax   (xh2 = v[2], f = fs)
+  double u1[6] = {0, 0, 0, 0, 0, 0};                              // c = coef  : dxdg, dg2, xh2, gsum, gmax, f   (ACCEL only)
+  double fs = 0.0;
+  // PERSISTENT form (round 4): a grid smaller than the number of chunks walks the chunk ids w0, w0 + grid, w0 + 2 grid, ... (ids are
+  // band-major: all strip groups of a row band, then the next band).  With short chunks the resident workgroups then sweep the image
+  // as ONE compact window of a few hundred rows that moves top to bottom -- the order in which the strip walk's traffic runs fastest
+  // (profiles/r04_tvshape.txt) -- while the sums stay in registers across chunks and are reduced once.  The assignment is static, so the
+  // summation order, hence every bit of the result, is fixed by (grid, rows per chunk).  grid = chunks: one chunk per workgroup (round 3).
+  for (uint32_t wg = w0; wg < p.nchunks; wg += gridDim.x) {
   const uint32_t sg = wg % p.strip_groups, rc = wg / p.strip_groups;
   const uint32_t i0 = rc * p.rows_wg;
   const uint32_t rows = min(p.rows_wg, p.H - i0);
@@ -934,12 +965,6 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
   const uint32_t cw = (first + lane + 2u * p.W - 2u) % p.W;       // lane L <-> image column first + L - 2 (periodic)
   const uint32_t c = first + lane - 2u;                           // valid as an index only for owning lanes
   const bool own = lane >= 2u && lane <= 61u && c < p.W;
-  const bool lag = ACCEL && p.cprev != 0.0;                       // uniform: the previous step extrapolated
-  const double rtau = 1.0 / p.tau;
-  double v[5] = {0, 0, 0, 0, 0};                                  // dxg0, dx2, xh2, g02, restart dot
-  double u0[4] = {0, 0, 0, 0};                                    // c = 0     : dxdg, dg2, gsum, gmax   (xh2 = v[2], f = fs)
-  double u1[6] = {0, 0, 0, 0, 0, 0};                              // c = coef  : dxdg, dg2, xh2, gsum, gmax, f   (ACCEL only)
-  double fs = 0.0;
 
   auto row_of = [&](int off) -> uint32_t { return tv_wrap_row(i0, off, p.H); };   // (i0 + off) mod H, periodic
   auto div_at = [&](d2 me, d2 below) -> double {                  // div of one field at (row, col) given the row below; right neighbour by shuffle
@@ -1059,7 +1084,57 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
     }
     asm volatile("" ::: "memory");
   };
-  if constexpr (NB == 3) {
+  if constexpr (RING > 0) {
+    static_assert(TV_U % 2 == 0, "the RING form pairs the rows of a trip for its b pieces");
+    constexpr uint32_t XB = (uint32_t)TV_U * 1024u;                       // the x1 rows of one trip
+    constexpr uint32_t BOFF = XB * (ACCEL ? 2u : 1u);                     // the b pieces follow the x1 (and x0) rows
+    constexpr uint32_t SLOT = BOFF + (uint32_t)TV_U * 512u;
+    constexpr int G1 = TV_U + TV_U / 2, G2 = 2 * TV_U + TV_U / 2;         // DMA instructions per trip without / with the P0 stream
+    __shared__ __attribute__((aligned(16))) unsigned char s_ring[4 * RING * SLOT];
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)s_ring;
+    const uint32_t ring = __builtin_amdgcn_readfirstlane(ring0 + wave * ((uint32_t)RING * SLOT));   // this wave's ring (LDS byte address)
+    const uint32_t cwb = (first + 2u * (lane & 31u) + 2u * p.W - 2u) % p.W;     // b piece: lane l of each half wave fetches pixels 2l, 2l+1 of the strip
+    const bool stores = __builtin_amdgcn_ballot_w64(own) != 0;            // this wave issues store instructions at all
+    const int ntrips = (total + TV_U - 1) / TV_U;
+    auto issue_trip = [&](int it) {                                       // DMA trip `it` into slot it % RING (rows past the chunk clamped)
+      const uint32_t slot = ring + (uint32_t)(it % RING) * SLOT;
+      uint64_t ro[TV_U];
+#pragma unroll
+      for (int q = 0; q < TV_U; ++q) ro[q] = (uint64_t)row_of(min(it * TV_U + q, total - 1) - 2) * p.W;
+#pragma unroll
+      for (int q = 0; q < TV_U; ++q) {
+        tv_glds16(reinterpret_cast<const d2*>(p.p1) + ro[q] + cw, slot + (uint32_t)q * 1024u);
+        if (lag) tv_glds16(reinterpret_cast<const d2*>(p.p0) + ro[q] + cw, slot + XB + (uint32_t)q * 1024u);
+      }
+#pragma unroll
+      for (int q = 0; q < TV_U; q += 2) tv_glds16(p.b + (lane < 32u ? ro[q] : ro[q + 1]) + cwb, slot + BOFF + (uint32_t)q * 512u);
+    };
+    auto read_trip = [&](Trip& T, int it) {
+      const uint32_t slot = ring + (uint32_t)(it % RING) * SLOT;
+#pragma unroll
+      for (int q = 0; q < TV_U; ++q) {
+        T.x1[q] = *(tv_lds_d2)(uintptr_t)(slot + (uint32_t)q * 1024u + lane * 16u);
+        T.x0[q] = (d2){0.0, 0.0};
+        if (lag) T.x0[q] = *(tv_lds_d2)(uintptr_t)(slot + XB + (uint32_t)q * 1024u + lane * 16u);
+        T.b[q] = *(tv_lds_f64)(uintptr_t)(slot + BOFF + (uint32_t)q * 512u + lane * 8u);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the slot may be refilled from here on
+    };
+    for (int it = 0; it < RING - 1; ++it) issue_trip(it);
+    for (int it = 0; it < ntrips; ++it) {
+      issue_trip(it + RING - 1);                                          // into the slot consumed by the previous iteration
+      // Younger than trip it's DMAs: the DMAs of the RING - 1 later trips and the stores of the RING - 1 trips consumed since (vmcnt
+      // counts loads, stores and LDS-DMA together, in issue order).  Only when every one of those trips stored all of its TV_U rows
+      // is the larger count exact; waiting for FEWER outstanding operations is always safe.
+      const bool full = stores && (it - (RING - 1)) * TV_U >= 3 && (it - 1) * TV_U + TV_U - 3 <= (int)rows;
+      if (lag) { if (full) tv_wait_vm<(RING - 1) * (G2 + TV_U)>(); else tv_wait_vm<(RING - 1) * G2>(); }
+      else { if (full) tv_wait_vm<(RING - 1) * (G1 + TV_U)>(); else tv_wait_vm<(RING - 1) * G1>(); }
+      Trip T0;
+      read_trip(T0, it);
+      eat_trip(T0, it * TV_U);
+    }
+    tv_wait_vm<0>();                                                      // the clamped DMAs past the chunk still target this wave's ring
+  } else if constexpr (NB == 3) {
     // three rotating trips: two stay in flight behind the one being consumed -- the shape that sustains this read/write mix
     // best in scripts/bench_mem/mixprobe.hip (in the burst form below the waves sit in s_waitcnt 65 % of their cycles)
     Trip T0, T1, T2;
@@ -1077,6 +1152,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       eat_trip(T0, t0);
     }
   }
+  }   // chunks of this workgroup
   // partials per workgroup: [0] fs [1..4] v0..v3 [5] rdot [6..8] u0 dxdg, dg2, gsum [9..13] u1 dxdg, dg2, xh2, gsum, f  [14] u0 gmax [15] u1 gmax
   {
     double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], u0[0], u0[1]};
@@ -1086,7 +1162,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
     { const double m0 = wave_max(u0[3]), m1 = wave_max(u1[4]); if (lane == 0) { s_scr[wave * 2] = m0; s_scr[wave * 2 + 1] = m1; } }
     __syncthreads();
     if (tid == 0) {
-      double* slot = p.red + (uint64_t)wg * 16;              // by logical id: the finaliser's summation order does not depend on the dealing
+      double* slot = p.red + (uint64_t)w0 * 16;              // by logical id: the finaliser's summation order does not depend on the dealing
 #pragma unroll
       for (int k = 0; k < 8; ++k) store_partial(slot + k, w[k]);
 #pragma unroll

@@ -21,7 +21,8 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
- TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD) = range(14)
+ TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
+ TUNE_TV_RING, TUNE_TV_SLOTS) = range(16)
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
 CREATE_RCCL_SHELL = 0x100          # or'ed into the dtype of fh_create_ex: the multi-device (RCCL) form even for a single device
@@ -81,6 +82,12 @@ _lib = None
 
 class HipError(RuntimeError):
     """Non-zero status from libfasta_hip.so (message = fh_last_error())."""
+
+
+class HipTimeout(HipError):
+    """The one-pass kernel's bounded hand-off spins ran out (scalar word 15 of the launch): the launch itself succeeded and left the
+    solver state untouched, the caller may fall back to K-fwd / K-adj.  The ONLY HipError a solver may recover from: every other
+    non-zero status (device fault, RCCL error, bad state) must propagate."""
 
 
 def load_library(path=None):
@@ -307,10 +314,10 @@ class HipContext:
         return bool(ok.value)
 
     def step(self, tau):
-        """One-pass K-fwd + K-adj (no acceleration).  Raises if the bounded spins timed out."""
+        """One-pass K-fwd + K-adj (no acceleration).  Raises HipTimeout if the bounded spins timed out."""
         self._call("fh_step", float(tau), self._scal_p)
         if self._scal[15] != 0.0:
-            raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
+            raise HipTimeout("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()
 
     def step_accel(self, tau, coef, restart):
@@ -318,7 +325,7 @@ class HipContext:
         dot (returned in S_RDOT) exceeds 1e-30.  Dense operator."""
         self._call("fh_step_accel", float(tau), float(coef), 1 if restart else 0, self._scal_p)
         if self._scal[15] != 0.0:
-            raise HipError("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
+            raise HipTimeout("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()
 
     def commit(self, save_best=False):

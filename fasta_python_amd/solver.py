@@ -229,7 +229,7 @@ class FBSolver:
                     s = c.step(tau)
                 self.fused_steps += 1
                 return s, s
-            except hip.HipError as exc:                                 # bounded-spin timeout
+            except hip.HipTimeout as exc:                               # bounded-spin timeout ONLY: any other status propagates
                 # (row-sharded runs all-reduce the timeout word with g1, so every rank gets here in the same iteration
                 # and the ranks' collective sequences stay aligned.)  The usual cause is a co-tenant on the GPU -- the launch
                 # needs every CU at once -- which may be gone later: fall back to K-fwd / K-adj now and try the one-pass

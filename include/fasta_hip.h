@@ -98,8 +98,14 @@ enum fh_tuning_key {
                                 trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto        */
   FH_TUNE_TV_XCD = 12,       /* z-free one-pass stencil sweep: deal the workgroup ids out XCD by XCD, so that strips that share halo
                                 cache lines share an L2 (0 = auto = 1 = on, 2 = off: plain blockIdx order)                    */
-  FH_TUNE_TV_LDS_PAD = 13    /* z-free one-pass stencil sweep: bytes of unused dynamic LDS per workgroup (0..65536): an occupancy
+  FH_TUNE_TV_LDS_PAD = 13,   /* z-free one-pass stencil sweep: bytes of unused dynamic LDS per workgroup (0..65536): an occupancy
                                 limiter for experiments -- 40960 => at most 4 workgroups per CU, 53248 => 3, 65536 => 2        */
+  FH_TUNE_TV_RING = 14,      /* z-free one-pass stencil sweep: 2 or 3 = trips prefetched by LDS-DMA into a per-wave ring of that many
+                                2-row slots (loads in flight cost no registers); 1 = register-staged trips (FH_TUNE_TV_PIPE);
+                                0 = auto.  Needs an even image width, otherwise the register form runs                        */
+  FH_TUNE_TV_SLOTS = 15      /* z-free one-pass stencil sweep, persistent form: launch at most this many workgroups per CU (1..8); each
+                                walks the chunk ids (FH_TUNE_TV_ROWS rows each, band-major) with the grid as its stride, so that the
+                                resident workgroups sweep the image as one compact moving window; 0 = one workgroup per chunk     */
 };
 
 /* ---- library / context -------------------------------------------------------------- */

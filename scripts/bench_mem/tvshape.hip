@@ -22,6 +22,9 @@ template <int NT> __device__ __forceinline__ void st(d2* p, d2 v) { if (NT) __bu
 struct Geo {
   uint32_t H, W, pitch, rows_wg, strip_groups, bands;   // bands = ceil(H / rows_wg)
   int xcd;
+  int up;          // 1 = sweep the chunk bottom to top
+  uint32_t stagger; // start delay step (x s_sleep 8) by workgroup id
+  uint32_t* queue; uint32_t nchunks;   // QUEUE variants
 };
 
 __device__ __forceinline__ uint32_t xcd_order(uint32_t b, uint32_t grid, int on) {
@@ -47,15 +50,25 @@ __device__ __forceinline__ d2 work(d2 v, double b) {
 }
 
 // ---- register-staged strip walk (the product's shape) -------------------------------------------------------------------
-template <int OWN, int U, int NB, int NTS, int LAYOUT, int ALU>
-__global__ __launch_bounds__(256) void k_strip(const d2* __restrict__ x, const double* __restrict__ b, d2* __restrict__ xp, const Geo g) {
+template <int OWN, int U, int NB, int NTS, int LAYOUT, int ALU, int MODE = 0, int NW = 4, int QUEUE = 0>
+__global__ __launch_bounds__(64 * NW) void k_strip(const d2* __restrict__ x, const double* __restrict__ b, d2* __restrict__ xp, const Geo g) {
   constexpr int HALO = OWN == 64 ? 0 : 2;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t wg = xcd_order(blockIdx.x, gridDim.x, g.xcd);
+  __shared__ uint32_t s_next;
+  uint32_t wg = xcd_order(blockIdx.x, gridDim.x, g.xcd);
+  if (g.stagger) { const uint32_t n = (blockIdx.x / 8u) % 16u * g.stagger; for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8); }
+  for (;;) {
+  if (QUEUE) {                                  // persistent workgroups pull chunk ids in order (band-major: a compact moving window)
+    __syncthreads();
+    if (threadIdx.x == 0) s_next = atomicAdd(g.queue, 1u);
+    __syncthreads();
+    wg = s_next;
+    if (wg >= g.nchunks) return;
+  }
   const uint32_t sg = wg % g.strip_groups, rc = wg / g.strip_groups;
   const uint32_t i0 = rc * g.rows_wg;
   const uint32_t rows = min(g.rows_wg, g.H - i0);
-  const uint32_t first = (sg * 4 + wave) * OWN;
+  const uint32_t first = (sg * NW + wave) * OWN;
   const uint32_t cw = (first + lane + 2u * g.W - HALO) % g.W;
   const uint32_t c = first + lane - HALO;
   const bool own = lane >= (uint32_t)HALO && lane < (uint32_t)(HALO + OWN) && c < g.W;
@@ -65,19 +78,20 @@ __global__ __launch_bounds__(256) void k_strip(const d2* __restrict__ x, const d
   auto load = [&](Trip& T, int t0) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-      const int s = min(t0 + q, total - 1) - HALO;
+      const int tt = min(t0 + q, total - 1);
+      const int s = (g.up ? total - 1 - tt : tt) - HALO;
       const uint64_t pix = (uint64_t)mem_row<LAYOUT>(row_of(s), g) * g.pitch + cw;
-      T.x[q] = x[pix];
-      T.b[q] = b[pix];
+      if (!(MODE & 1)) { T.x[q] = x[pix]; T.b[q] = b[pix]; } else { T.x[q] = (d2){(double)pix, 1.0}; T.b[q] = (double)cw; }
     }
     asm volatile("" ::: "memory");
   };
   auto store = [&](const Trip& T, int t0) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-      const int s = t0 + q - HALO;
+      const int s = (g.up ? total - 1 - (t0 + q) : t0 + q) - HALO;
       const d2 v = work<ALU>(T.x[q], T.b[q]);
-      if (t0 + q < total && own && s >= 0 && s < (int)rows) st<NTS>(xp + (uint64_t)mem_row<LAYOUT>(i0 + s, g) * g.pitch + c, v);
+      if (MODE & 2) { if (v.x == 1.2345e300) xp[0] = v; }
+      else if (t0 + q < total && own && s >= 0 && s < (int)rows) st<NTS>(xp + (uint64_t)mem_row<LAYOUT>(i0 + s, g) * g.pitch + c, v);
     }
     asm volatile("" ::: "memory");
   };
@@ -91,6 +105,8 @@ __global__ __launch_bounds__(256) void k_strip(const d2* __restrict__ x, const d
     }
   } else {
     for (int t0 = 0; t0 < total; t0 += U) { Trip T0; load(T0, t0); store(T0, t0); }
+  }
+  if (!QUEUE) return;
   }
 }
 
@@ -130,7 +146,8 @@ __global__ __launch_bounds__(256) void k_strip_lds(const d2* __restrict__ x, con
   // first strip's two halo lanes wrap: they read a neighbouring pixel instead (traffic identical).
   auto issue = [&](int pr) {                                             // DMA pair pr into slot pr % D
     const uint32_t slot = ring + (uint32_t)(pr % D) * SLOT;
-    const int sa = min(2 * pr, total - 1) - HALO, sb = min(2 * pr + 1, total - 1) - HALO;
+    const int ta = min(2 * pr, total - 1), tb = min(2 * pr + 1, total - 1);
+    const int sa = (g.up ? total - 1 - ta : ta) - HALO, sb = (g.up ? total - 1 - tb : tb) - HALO;
     const uint64_t ra = (uint64_t)mem_row<LAYOUT>(row_of(sa), g) * g.pitch, rb = (uint64_t)mem_row<LAYOUT>(row_of(sb), g) * g.pitch;
     glds16(x + ra + cw, slot);
     glds16(x + rb + cw, slot + 1024);
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(256) void k_strip_lds(const d2* __restrict__ x, con
     // younger than pair pr's three DMAs: the 3 DMAs of each of the D-1 later pairs and, in the steady state, the 2 stores of each of
     // the D-1 pairs consumed since (vmcnt counts loads, stores and LDS-DMA together, in issue order).  Waiting for too FEW
     // outstanding operations is always safe, so the store-free cases use the smaller count.
-    if (stores && pr >= D && 2 * pr + 1 - HALO < (int)rows) wait_vm<3 * (D - 1) + 2 * (D - 1)>(); else wait_vm<3 * (D - 1)>();
+    if (stores && pr >= D && 2 * pr + 1 - HALO < (int)rows && !g.up) wait_vm<3 * (D - 1) + 2 * (D - 1)>(); else wait_vm<3 * (D - 1)>();
     const uint32_t slot = ring + (uint32_t)(pr % D) * SLOT;
     const d2 xa = *reinterpret_cast<const __attribute__((address_space(3))) d2*>((uintptr_t)(slot + lane * 16));
     const d2 xb = *reinterpret_cast<const __attribute__((address_space(3))) d2*>((uintptr_t)(slot + 1024 + lane * 16));
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(256) void k_strip_lds(const d2* __restrict__ x, con
     const double bb = *reinterpret_cast<const __attribute__((address_space(3))) double*>((uintptr_t)(slot + 2560 + lane * 8));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const d2 va = work<ALU>(xa, ba), vb = work<ALU>(xb, bb);
-    const int sa = 2 * pr - HALO, sb = 2 * pr + 1 - HALO;
+    const int sa = (g.up ? total - 1 - 2 * pr : 2 * pr) - HALO, sb = (g.up ? total - 2 - 2 * pr : 2 * pr + 1) - HALO;
     if (own && sa >= 0 && sa < (int)rows) st<NTS>(xp + (uint64_t)mem_row<LAYOUT>(i0 + sa, g) * g.pitch + c, va);
     if (own && sb >= 0 && sb < (int)rows && 2 * pr + 1 < total) st<NTS>(xp + (uint64_t)mem_row<LAYOUT>(i0 + sb, g) * g.pitch + c, vb);
     asm volatile("" ::: "memory");
@@ -173,6 +190,20 @@ template <typename F> static int run(const char* name, double bytes, F launch) {
   return 0;
 }
 
+template <typename F> static int run_i(const char* name, double bytes, F launch) {   // launch(i): i = running launch index
+  int it = 0;
+  launch(it++); launch(it++); CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+  float best = 1e30f, tot = 0.f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0)); for (int i = 0; i < 10; ++i) launch(it++); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10; tot += ms; if (ms < best) best = ms;
+  }
+  printf("%-96s best %7.4f ms %6.0f GB/s   mean %7.4f ms\n", name, best, bytes / best / 1e6, tot / 3);
+  fflush(stdout);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int set = argc > 1 ? atoi(argv[1]) : 0;
   const uint32_t H = 8192, W = 8192;
@@ -184,7 +215,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   char name[200];
   auto geo = [&](int own, uint32_t rows, uint32_t pitch, int xcd) {
-    Geo g; g.H = H; g.W = W; g.pitch = pitch; g.rows_wg = rows; g.strip_groups = ((W + own - 1) / own + 3) / 4; g.bands = (H + rows - 1) / rows; g.xcd = xcd;
+    Geo g; g.H = H; g.W = W; g.pitch = pitch; g.rows_wg = rows; g.strip_groups = ((W + own - 1) / own + 3) / 4; g.bands = (H + rows - 1) / rows; g.xcd = xcd; g.up = 0; g.stagger = 0; g.queue = nullptr; g.nchunks = 0;
     return g;
   };
 #define STRIP(OWN, U, NB, NTS, LAYOUT, ALU, ROWS, PITCH, XCD) do { const Geo g = geo(OWN, ROWS, PITCH, XCD); const uint32_t grid = g.strip_groups * g.bands; \
@@ -223,6 +254,83 @@ int main(int argc, char** argv) {
     LSTRIP(60, 2, 1, 0, 170, 228, 8192, 1); LSTRIP(60, 3, 1, 0, 170, 228, 8192, 1); LSTRIP(60, 4, 1, 0, 170, 228, 8192, 1);
     LSTRIP(60, 2, 1, 2, 170, 228, 8192, 1); LSTRIP(60, 3, 1, 2, 170, 228, 8192, 1); LSTRIP(60, 4, 1, 2, 170, 228, 8192, 1);
     LSTRIP(64, 3, 1, 2, 170, 228, 8192, 1);
+  }
+  if (set == 0 || set == 4) {
+    printf("=== (4) what the stand-in costs alone: no loads / no stores / neither (register staging, NB = 1)\n");
+#define MSTRIP(ALU, MODE) do { const Geo g = geo(60, 228, 8192, 1); const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60 U=2 NB=1 alu=%3d %s", ALU, MODE == 3 ? "no loads, no stores" : MODE == 1 ? "no loads" : MODE == 2 ? "no stores" : "complete"); \
+    if (run(name, 40.0 * P, [&] { k_strip<60, 2, 1, 1, 0, ALU, MODE><<<grid, 256>>>(x, b, xp, g); })) return 1; } while (0)
+    MSTRIP(170, 3); MSTRIP(170, 1); MSTRIP(170, 2); MSTRIP(170, 0); MSTRIP(120, 3); MSTRIP(240, 3); MSTRIP(240, 0); MSTRIP(0, 1); MSTRIP(0, 2);
+  }
+  if (set == 0 || set == 5) {
+    printf("=== (5) output of launch i = input of launch i+1 (as the solver's buffers rotate); sweep direction fixed or alternating\n");
+#define PSTRIP(U, NB, ALU, ALT, XSWAP) do { Geo g = geo(60, 228, 8192, 1); const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60 U=%d NB=%d alu=%3d buffers %s, direction %s", U, NB, ALU, XSWAP ? "rotate" : "fixed ", ALT ? "alternates" : "fixed"); \
+    if (run_i(name, 40.0 * P, [&](int i) { g.up = ALT ? (i & 1) : 0; const bool sw = XSWAP && (i & 1); \
+        k_strip<60, U, NB, 1, 0, ALU><<<grid, 256>>>(sw ? xp : x, b, sw ? x : xp, g); })) return 1; } while (0)
+    PSTRIP(2, 1, 0, 0, 0); PSTRIP(2, 1, 0, 0, 1); PSTRIP(2, 1, 0, 1, 1); PSTRIP(2, 1, 0, 1, 0);
+    PSTRIP(2, 3, 0, 0, 1); PSTRIP(2, 3, 0, 1, 1);
+    PSTRIP(2, 1, 170, 0, 1); PSTRIP(2, 1, 170, 1, 1); PSTRIP(2, 3, 170, 0, 1); PSTRIP(2, 3, 170, 1, 1);
+#define PLSTRIP(D, ALU, ALT) do { Geo g = geo(60, 228, 8192, 1); const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "lds  own=60 D=%d alu=%3d buffers rotate, direction %s", D, ALU, ALT ? "alternates" : "fixed"); \
+    if (run_i(name, 40.0 * P, [&](int i) { g.up = ALT ? (i & 1) : 0; const bool sw = (i & 1); \
+        k_strip_lds<60, D, 1, 0, ALU><<<grid, 256, 4 * D * 3072>>>(sw ? xp : x, b, sw ? x : xp, g); })) return 1; } while (0)
+    PLSTRIP(3, 0, 0); PLSTRIP(3, 0, 1); PLSTRIP(3, 170, 0); PLSTRIP(3, 170, 1);
+  }
+  if (set == 0 || set == 6) {
+    printf("=== (6) LDS ring: chunk rows / occupancy\n");
+    LSTRIP(60, 2, 1, 0, 170, 128, 8192, 1); LSTRIP(60, 2, 1, 0, 170, 200, 8192, 1); LSTRIP(60, 3, 1, 0, 170, 285, 8192, 1); LSTRIP(60, 4, 1, 0, 170, 380, 8192, 1);
+    LSTRIP(60, 6, 1, 0, 170, 570, 8192, 1); LSTRIP(60, 8, 1, 0, 170, 1140, 8192, 1);
+    LSTRIP(60, 2, 1, 0, 0, 128, 8192, 1); LSTRIP(60, 3, 1, 0, 0, 285, 8192, 1); LSTRIP(60, 6, 1, 0, 0, 570, 8192, 1); LSTRIP(60, 8, 1, 0, 0, 1140, 8192, 1);
+  }
+  if (set == 0 || set == 7) {
+    printf("=== (7) traffic only and with the stand-in: waves per workgroup, chunk rows (several rounds of workgroups), staggered starts, persistent workgroups pulling chunks in order\n");
+    uint32_t* queue; CK(hipMalloc(&queue, 64)); 
+#define WSTRIP(NW, U, NB, ALU, ROWS, STAG) do { Geo g = geo(60, ROWS, 8192, 1); g.strip_groups = ((W + 59) / 60 + NW - 1) / NW; g.stagger = STAG; const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60 waves/wg=%d U=%d NB=%d alu=%3d rows=%3d stagger=%d grid=%u", NW, U, NB, ALU, ROWS, STAG, grid); \
+    if (run(name, 40.0 * P, [&] { k_strip<60, U, NB, 1, 0, ALU, 0, NW><<<grid, 64 * NW>>>(x, b, xp, g); })) return 1; } while (0)
+#define QSTRIP(NW, U, NB, ALU, ROWS, PERCU, XCD) do { Geo g = geo(60, ROWS, 8192, XCD); g.strip_groups = ((W + 59) / 60 + NW - 1) / NW; g.queue = queue; g.nchunks = g.strip_groups * g.bands; const uint32_t grid = 256 * PERCU; \
+    snprintf(name, sizeof name, "reg  own=60 waves/wg=%d U=%d NB=%d alu=%3d rows=%3d QUEUE %d wg/CU, %u chunks", NW, U, NB, ALU, ROWS, PERCU, g.nchunks); \
+    if (run(name, 40.0 * P, [&] { hipMemsetAsync(queue, 0, 4, 0); k_strip<60, U, NB, 1, 0, ALU, 0, NW, 1><<<grid, 64 * NW>>>(x, b, xp, g); })) return 1; } while (0)
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0) {
+        WSTRIP(4, 2, 1, 0, 228, 0); WSTRIP(2, 2, 1, 0, 228, 0); WSTRIP(1, 2, 1, 0, 228, 0); WSTRIP(4, 2, 3, 0, 228, 0); WSTRIP(2, 2, 3, 0, 228, 0); WSTRIP(1, 2, 3, 0, 228, 0);
+        WSTRIP(4, 2, 1, 0, 32, 0); WSTRIP(4, 2, 1, 0, 64, 0); WSTRIP(4, 2, 1, 0, 128, 0); WSTRIP(4, 2, 3, 0, 32, 0); WSTRIP(4, 2, 3, 0, 64, 0); WSTRIP(1, 2, 3, 0, 64, 0);
+        WSTRIP(4, 2, 1, 0, 228, 4); WSTRIP(4, 2, 1, 0, 228, 16); WSTRIP(4, 2, 1, 0, 228, 64); WSTRIP(4, 2, 3, 0, 228, 16);
+        QSTRIP(4, 2, 1, 0, 32, 5, 0); QSTRIP(4, 2, 1, 0, 64, 5, 0); QSTRIP(4, 2, 3, 0, 32, 5, 0); QSTRIP(4, 2, 3, 0, 64, 5, 0); QSTRIP(4, 2, 3, 0, 64, 8, 0); QSTRIP(4, 2, 1, 0, 64, 8, 0); QSTRIP(4, 2, 1, 0, 16, 5, 0);
+      } else {
+        WSTRIP(4, 2, 1, 170, 228, 0); WSTRIP(2, 2, 1, 170, 228, 0); WSTRIP(1, 2, 1, 170, 228, 0); WSTRIP(4, 2, 3, 170, 228, 0); WSTRIP(1, 2, 3, 170, 228, 0);
+        WSTRIP(4, 2, 1, 170, 32, 0); WSTRIP(4, 2, 1, 170, 64, 0); WSTRIP(4, 2, 3, 170, 64, 0);
+        WSTRIP(4, 2, 1, 170, 228, 16); WSTRIP(4, 2, 3, 170, 228, 16);
+        QSTRIP(4, 2, 1, 170, 32, 5, 0); QSTRIP(4, 2, 1, 170, 64, 5, 0); QSTRIP(4, 2, 3, 170, 64, 5, 0);
+      }
+    }
+  }
+  if (set == 8) {
+    printf("=== (8) as (7) with every launch capped at 5 workgroups per CU (32 KiB of dynamic LDS each, as the product's registers cap it)\n");
+    uint32_t* queue; CK(hipMalloc(&queue, 64));
+    const int CAP = 32768;
+#define WSTRIP8(U, NB, ALU, ROWS) do { Geo g = geo(60, ROWS, 8192, 1); const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60 U=%d NB=%d alu=%3d rows=%3d grid=%u (5 wg/CU cap)", U, NB, ALU, ROWS, grid); \
+    if (run(name, 40.0 * P, [&] { k_strip<60, U, NB, 1, 0, ALU, 0, 4><<<grid, 256, CAP>>>(x, b, xp, g); })) return 1; } while (0)
+#define QSTRIP8(U, NB, ALU, ROWS, XCD) do { Geo g = geo(60, ROWS, 8192, XCD); g.queue = queue; g.nchunks = g.strip_groups * g.bands; const uint32_t grid = 1280; \
+    snprintf(name, sizeof name, "reg  own=60 U=%d NB=%d alu=%3d rows=%3d QUEUE 1280 wgs (5/CU cap), %u chunks", U, NB, ALU, ROWS, g.nchunks); \
+    if (run(name, 40.0 * P, [&] { hipMemsetAsync(queue, 0, 4, 0); k_strip<60, U, NB, 1, 0, ALU, 0, 4, 1><<<grid, 256, CAP>>>(x, b, xp, g); })) return 1; } while (0)
+    WSTRIP8(2, 1, 0, 228); WSTRIP8(2, 3, 0, 228); WSTRIP8(2, 1, 0, 32); WSTRIP8(2, 1, 0, 64); WSTRIP8(2, 3, 0, 32);
+    QSTRIP8(2, 1, 0, 16, 0); QSTRIP8(2, 1, 0, 32, 0); QSTRIP8(2, 1, 0, 64, 0); QSTRIP8(2, 3, 0, 16, 0); QSTRIP8(2, 3, 0, 32, 0); QSTRIP8(2, 1, 0, 8, 0);
+    WSTRIP8(2, 1, 170, 228); WSTRIP8(2, 3, 170, 228); WSTRIP8(2, 1, 170, 32); WSTRIP8(2, 1, 170, 64);
+    QSTRIP8(2, 1, 170, 16, 0); QSTRIP8(2, 1, 170, 32, 0); QSTRIP8(2, 1, 170, 64, 0); QSTRIP8(2, 3, 170, 32, 0);
+    WSTRIP8(2, 1, 240, 228); WSTRIP8(2, 3, 240, 228); QSTRIP8(2, 1, 240, 32, 0); QSTRIP8(2, 1, 240, 64, 0); QSTRIP8(2, 3, 240, 64, 0);
+  }
+  if (set == 9) {
+    printf("=== (9) 5 wg/CU cap, one round of 228-row chunks: small start staggers (x 0.25 us, by (id / 8) %% 16); traffic only and alu=170\n");
+    const int CAP = 32768;
+#define SSTRIP(U, NB, ALU, STAG) do { Geo g = geo(60, 228, 8192, 1); g.stagger = STAG; const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60 U=%d NB=%d alu=%3d rows=228 stagger=%d (5 wg/CU cap)", U, NB, ALU, STAG); \
+    if (run(name, 40.0 * P, [&] { k_strip<60, U, NB, 1, 0, ALU, 0, 4><<<grid, 256, CAP>>>(x, b, xp, g); })) return 1; } while (0)
+    SSTRIP(2, 1, 0, 0); SSTRIP(2, 1, 0, 1); SSTRIP(2, 1, 0, 2); SSTRIP(2, 3, 0, 0); SSTRIP(2, 3, 0, 1); SSTRIP(2, 3, 0, 2);
+    SSTRIP(2, 1, 170, 0); SSTRIP(2, 1, 170, 1); SSTRIP(2, 1, 170, 2); SSTRIP(2, 3, 170, 0); SSTRIP(2, 3, 170, 1);
+    SSTRIP(4, 3, 0, 0); SSTRIP(4, 1, 0, 0); SSTRIP(8, 1, 0, 0); SSTRIP(4, 3, 170, 0); SSTRIP(4, 1, 170, 0);
   }
   return 0;
 }

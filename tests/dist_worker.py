@@ -59,7 +59,7 @@ class ShardedFakeContext(FakeContext):
         self.one_pass_launches += 1
         if float(self.allreduce(np.array([local]))[0]) != 0.0:       # the word every rank reads back (scalars[15])
             self.timeout_raised_at = k
-            raise hip.HipError("fused one-pass kernel: team hand-off timed out (injected)")
+            raise hip.HipTimeout("fused one-pass kernel: team hand-off timed out (injected)")
         return scalars
 
     def step(self, tau):

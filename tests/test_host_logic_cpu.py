@@ -135,7 +135,7 @@ def test_one_pass_kernel_is_retried_with_backoff_after_a_timeout():
             launches.append(len(launches))
             out = real_step(tau)                          # (the collectives of a timed-out launch still complete)
             if launches[-1] in fail_at:
-                raise hip.HipError("fused one-pass kernel: team hand-off timed out (injected)")
+                raise hip.HipTimeout("fused one-pass kernel: team hand-off timed out (injected)")
             return out
         op.ctx.step = step
         ls, reg = fa.LeastSquares(d["b"]), fa.Shrink(float(d["mu"]))
@@ -156,3 +156,42 @@ def test_one_pass_kernel_is_retried_with_backoff_after_a_timeout():
     assert got.iteration_count == ref.iteration_count == 40 and got.backtracks == ref.backtracks
     np.testing.assert_allclose(got.residuals, ref.residuals, rtol=1e-12)
     np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
+
+
+def test_only_a_typed_timeout_is_recovered_from():
+    """VERDICT r3 / 'typed timeout': the driver falls back to K-fwd / K-adj for `hip.HipTimeout` alone (the launch succeeded, its hand-off
+    spins ran out).  Any other non-zero status of the one-pass launch -- a device fault, an RCCL error on one rank -- is NOT a reason to
+    change the launch (and, in a sharded run, the collective) sequence: it must reach the caller."""
+    from fasta_python_amd import hip
+    assert issubclass(hip.HipTimeout, hip.HipError)
+    meta, z = H.load_case("sparse_ls_64x128_adaptive")
+    d = H.case_data(meta, z)
+    for exc_type, recovered in ((hip.HipTimeout, True), (hip.HipError, False)):
+        for accelerate in (False, True):
+            op = FakeDenseMap(d["A"], fused_kind=1)
+            name = "step_accel" if accelerate else "step"
+            real, count = getattr(op.ctx, name), [0]
+
+            def launch(*args, real=real, count=count, exc_type=exc_type):
+                count[0] += 1
+                out = real(*args)
+                if count[0] == 3:
+                    raise exc_type("[700] injected: an illegal address was encountered" if exc_type is hip.HipError else "injected timeout")
+                return out
+            setattr(op.ctx, name, launch)
+            ls, reg = fa.LeastSquares(d["b"]), fa.Shrink(float(d["mu"]))
+            np.random.seed(meta["solver_seed"])
+            solver = fa.FBSolver(op, ls, reg, np.zeros(d["A"].shape[1]), verbose=False, max_iters=8, tolerance=0.0,
+                                 accelerate=accelerate).setup()
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                if recovered:
+                    while not solver.step():
+                        pass
+                    assert solver.i == 8 and op.ctx.calls["fwd"] >= 1          # fell back, finished the solve
+                else:
+                    with pytest.raises(hip.HipError, match="illegal address") as info:
+                        while not solver.step():
+                            pass
+                    assert not isinstance(info.value, hip.HipTimeout)
+                    assert solver.use_fused and op.ctx.calls["fwd"] == 0       # no silent switch to the two-launch path
