@@ -591,7 +591,9 @@ def main(argv=None):
 
     # device of this rank: LOCAL_RANK, folded onto the devices that exist (a node with fewer GPUs than ranks -- e.g. a rehearsal of
     # `--gpus 2` on a one-GPU box -- puts several ranks on one device; whether RCCL accepts that is RCCL's call)
-    grp.local_rank = grp.local_rank % max(1, hip.device_count())
+    ndev = max(1, hip.device_count())
+    ranks_on_my_device = len([r for r in range(grp.world) if r % ndev == grp.local_rank % ndev]) if grp.world > ndev else 1
+    grp.local_rank = grp.local_rank % ndev
     fused = FUSED_OPT[args.fused]
     if args.workload == "tv":
         if grp.world != 1:
@@ -607,6 +609,10 @@ def main(argv=None):
     for item in filter(None, args.tune.split(",")):
         k, v = item.split("=")
         tuning[int(k)] = int(v)
+    if ranks_on_my_device > 1 and hip.TUNE_FUSED_CUS not in tuning:
+        # ranks that SHARE a device each take their share of its CUs for the one-pass kernel (whole-CU workgroups, all resident at
+        # once): the ranks' grids are then co-resident by construction instead of timing each other out
+        tuning[hip.TUNE_FUSED_CUS] = max(32, hip.device_cus(grp.local_rank) // ranks_on_my_device // 32 * 32)
     inproc_devices = None
     if args.inproc:
         inproc_devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
@@ -641,7 +647,7 @@ def main(argv=None):
     # read-only ceiling on the same buffer: the probe with one and with two persistent workgroups per CU (the one-pass kernel itself
     # can only have one: it uses the whole register file), the better of the two is the ceiling quoted
     ceilings = {}
-    ncu = 256
+    ncu = ctx.cu_count()[0]
     for wg_per_cu in (1, 2):
         ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, ncu * wg_per_cu)
         ms, ceil_bytes = ctx.stream_read_ms(3)

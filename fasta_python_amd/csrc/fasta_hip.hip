@@ -259,7 +259,12 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (c->lazy && (value ? 1 : 0) != c->tv_zfree)
         return fail(FH_E_STATE, "TV_ZFREE cannot change while a one-pass accelerated stencil solve is in flight (call fh_init / fh_set_vector(X0) first)");
       c->tv_zfree = value ? 1 : 0; return 0;
+    case FH_TUNE_FUSED_CUS:
+      if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
+      if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->fused_kind_agreed = -1; c->slots_sig = 0; }
+      return 0;
     case FH_TUNE_FUSED_VARIANT:
+      if (((int)value ^ c->fused_variant) & 128) c->fused_kind_agreed = -1;
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
@@ -655,13 +660,45 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   //     prologue, grid barrier, epilogue), which two short launches under one sync beat on a small matrix
   //     (profiles/r02_fused_crossover.txt: 512 x 1024 35.6 vs 34.9 us, 2048^2 46 vs 53 us, 1024 x 8192 60 vs 63 us, 4096^2 77 vs 76 us)
   int ppt = c->op == OP_DENSE ? fused_ppt(c) : 0;
-  // The dense one-pass kernel needs its whole grid (one workgroup per CU the device REPORTS) co-resident: probed once per context
+  // The dense one-pass kernel needs its whole grid (one workgroup per CU it uses) co-resident: probed once per context
   // (co_resident above); "unsupported" up front instead of a bounded-spin timeout on the first launch (the timeout stays as the
   // safety net for CUs that disappear later).
   if (ppt && !co_resident(c)) ppt = 0;
-  *yes = c->op == OP_STENCIL ? (row_sharded(c) ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
+  int kind = c->op == OP_STENCIL ? (row_sharded(c) ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
+  // One process per GPU: the verdict must be the SAME on every rank -- a rank whose probe said no would otherwise take fh_fwd /
+  // fh_adj (exchanges of 1, then n + 1 doubles) while its peers take fh_step (one exchange of n + 3): mismatched collectives, i.e. a
+  // hang.  So the ranks agree once per context state: counts of "0" and "3" verdicts are summed over the communicator; any 0 makes it
+  // 0 everywhere, else any 3 makes it 3.  This makes fh_fused_supported a COLLECTIVE call on a context with a communicator (every
+  // rank calls it at the same point: FBSolver.setup does).
+  // (the shards of an in-process multi-device context are combined by their shell above, in one process: nothing to agree on)
+  if (c->comm && !c->owner && c->op == OP_DENSE) {
+    if (c->fused_kind_agreed < 0) {
+      double* w = c->dscal + FH_NSCALARS + 8;            // scratch behind the scalar block
+      const double mine[2] = {kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0};
+      FH_TRY(use_device(c));
+      HIP_TRY(hipMemcpyAsync(w, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+      FH_TRY(sum_over_shards(c, [w](fh_ctx*) { return w; }, 2));
+      double all[2] = {1.0, 0.0};
+      HIP_TRY(hipMemcpyAsync(all, w, sizeof all, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->fused_kind_agreed = all[0] != 0.0 ? 0 : (all[1] != 0.0 ? 3 : kind);
+    }
+    kind = c->fused_kind_agreed;
+  }
+  *yes = kind;
   return 0;
 }
+
+// CUs the device reports and CUs the one-pass dense kernel is launched on (FH_TUNE_FUSED_CUS)
+extern "C" int fh_cu_count(fh_ctx* c, int* device_cus, int* one_pass_cus) {
+  if (!c || !device_cus || !one_pass_cus) return fail(FH_E_ARG, "null argument");
+  if (!c->shards.empty()) c = c->shards[0];
+  *device_cus = c->ncu;
+  *one_pass_cus = fused_ncu(c);
+  return 0;
+}
+// the library the RCCL entry points were taken from ("" before the first communicator): the system's RCCL or $FASTA_RCCL_LIB
+extern "C" const char* fh_comm_library(void) { return g_rccl_path; }
 
 // One-pass iteration of the dense operator on every row block (`accel` = 0: fh_step; 1: fh_step_accel): local launch on every
 // shard -> ONE sum over the row blocks of g1 with the local loss sums and the timeout word appended (every shard / rank then sees
@@ -837,6 +874,7 @@ extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) 
   memcpy(&id, id128, sizeof(id));
   NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
   c->nranks = nranks; c->rank = rank;
+  c->fused_kind_agreed = -1;
   return 0;
 }
 
@@ -858,6 +896,7 @@ extern "C" int fh_comm_destroy(fh_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     NCCL_TRY(g_rccl.CommDestroy(c->comm));
     c->comm = nullptr; c->nranks = 1; c->rank = 0;
+    c->fused_kind_agreed = -1;
   }
   return 0;
 }

@@ -52,16 +52,21 @@ static RcclApi g_rccl;
 static const int kNcclFloat64 = 8;   // ncclDouble
 static const int kNcclSum = 0;       // ncclSum
 
+static char g_rccl_path[512] = "";     // what rccl_load() opened (fh_comm_library)
 static int rccl_load() {
   if (g_rccl.lib) return 0;
-  // FASTA_RCCL_LIB names another library with RCCL's entry points (a different RCCL build; the tests' multi-process stand-in)
-  const char* names[] = {getenv("FASTA_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  // FASTA_RCCL_LIB names another library with RCCL's entry points (a different RCCL build; the tests' multi-process stand-in).
+  // A substitution is never silent: one line on stderr, and fh_comm_library() reports the path that was opened.
+  const char* sub = getenv("FASTA_RCCL_LIB");
+  const char* names[] = {sub, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
   for (const char* nm : names) {
     if (!nm || !*nm) continue;
     g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (g_rccl.lib) break;
+    if (g_rccl.lib) { snprintf(g_rccl_path, sizeof g_rccl_path, "%s", nm); break; }
+    if (nm == sub) return fail(FH_E_RCCL, "FASTA_RCCL_LIB=%s cannot be opened: %s (unset it to use the system's RCCL)", nm, dlerror());
   }
   if (!g_rccl.lib) return fail(FH_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+  if (sub && *sub) fprintf(stderr, "libfasta_hip: collectives come from FASTA_RCCL_LIB=%s, not from the system's RCCL\n", sub);
 #define SYM(field, name)                                                      \
   *(void**)(&g_rccl.field) = dlsym(g_rccl.lib, name);                         \
   if (!g_rccl.field) return fail(FH_E_RCCL, "librccl lacks symbol %s", name)
@@ -139,7 +144,7 @@ struct fh_ctx {
   // workspace
   double* ws = nullptr;
   size_t ws_bytes = 0;
-  unsigned* counters = nullptr;      // 4096 words, zeroed at creation; kernels leave them zero
+  unsigned* counters = nullptr;      // kCounterWords (8192) words, zeroed at creation; kernels leave them zero
   double* dscal = nullptr;           // FH_NSCALARS + 16 doubles on device
   double* hscal = nullptr;           // pinned, device-mapped host block: single-GPU launches write their scalars here
   double* hscal_dev = nullptr;       // device-side address of hscal
@@ -179,7 +184,9 @@ struct fh_ctx {
   fh_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
   int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
-  int coresident = -1;       // -1 = not probed yet; 1 / 0 = ncu workgroups can / cannot run side by side (co_resident())
+  int coresident = -1;       // -1 = not probed yet; 1 / 0 = fused_ncu() workgroups can / cannot run side by side (co_resident())
+  int fused_cus = 0;         // FH_TUNE_FUSED_CUS: the one-pass dense kernel uses at most this many CUs (0 = all the device reports)
+  int fused_kind_agreed = -1; // fh_fused_supported's verdict after the ranks of the communicator agreed on it (-1 = not yet)
   // ---- in-process row sharding (fh_create_ex with ndev > 1; SURVEY.md 8(b)/(e): one host thread, one context per device) ----
   // A context created over several devices is a SHELL: it owns one child context per entry of dev_ids (`shards`), each holding
   // a contiguous block of rows of A and the matching slice of b / z, while x, g, xhat are replicated.  Every entry point of the
@@ -339,12 +346,16 @@ static int sum_over_shards(fh_ctx* c, Sel sel, size_t count, Sel2 sel2, size_t c
   if (c->shards.empty()) {
     if (!c->comm) return 0;
     t_begin(c, FH_K_COMM);
+    // (an error inside a group must still close it: the thread's group depth would otherwise stay open and every later collective,
+    // the fallback path's included, would be queued and never run)
     if (count2) NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllReduce(sel(c), sel(c), count, kNcclFloat64, kNcclSum, c->comm, c->stream));
+    int r1 = g_rccl.AllReduce(sel(c), sel(c), count, kNcclFloat64, kNcclSum, c->comm, c->stream);
     if (count2) {
-      NCCL_TRY(g_rccl.AllReduce(sel2(c), sel2(c), count2, kNcclFloat64, kNcclSum, c->comm, c->stream));
-      NCCL_TRY(g_rccl.GroupEnd());
+      if (r1 == 0) r1 = g_rccl.AllReduce(sel2(c), sel2(c), count2, kNcclFloat64, kNcclSum, c->comm, c->stream);
+      const int r2 = g_rccl.GroupEnd();
+      if (r1 == 0) r1 = r2;
     }
+    if (r1 != 0) return fail(20000 + r1, "ncclAllReduce over the row blocks failed: %s", g_rccl.GetErrorString(r1));
     t_end(c, FH_K_COMM);
     return 0;
   }
@@ -366,11 +377,13 @@ static int sum_over_shards(fh_ctx* c, Sel sel, size_t count, Sel2 sel2, size_t c
   }
   for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_begin(s, FH_K_COMM); }
   NCCL_TRY(g_rccl.GroupStart());
+  int rg = 0;                                            // first error; the group is closed whatever happens
   for (fh_ctx* s : c->shards) {
-    NCCL_TRY(g_rccl.AllReduce(sel(s), sel(s), count, kNcclFloat64, kNcclSum, s->comm, s->stream));
-    if (count2) NCCL_TRY(g_rccl.AllReduce(sel2(s), sel2(s), count2, kNcclFloat64, kNcclSum, s->comm, s->stream));
+    if (rg == 0) rg = g_rccl.AllReduce(sel(s), sel(s), count, kNcclFloat64, kNcclSum, s->comm, s->stream);
+    if (rg == 0 && count2) rg = g_rccl.AllReduce(sel2(s), sel2(s), count2, kNcclFloat64, kNcclSum, s->comm, s->stream);
   }
-  NCCL_TRY(g_rccl.GroupEnd());
+  { const int re = g_rccl.GroupEnd(); if (rg == 0) rg = re; }
+  if (rg != 0) return fail(20000 + rg, "grouped ncclAllReduce over the row blocks failed: %s", g_rccl.GetErrorString(rg));
   for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); t_end(s, FH_K_COMM); }
   return 0;
 }

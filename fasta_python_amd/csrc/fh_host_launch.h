@@ -338,9 +338,12 @@ static const FusedEntry* fused_lookup(const FusedShape& sh, int f32) {
     if (e.ppt == sh.ppt && e.pipe == sh.pipe && e.team == sh.team && e.xlds == sh.xlds && e.nbo == sh.nbo && e.f32 == f32) return &e;
   return nullptr;
 }
+// CUs (= workgroups) of the one-pass dense launch.  FH_TUNE_FUSED_CUS caps them, so that several one-pass grids can be co-resident
+// on ONE device: two solves side by side, or -- in the tests -- the ranks of a row-sharded run that share a GPU (K ranks x ncu / K CUs).
+static int fused_ncu(fh_ctx* c) { return c->fused_cus > 0 ? std::min(c->fused_cus, std::max(1, c->ncu)) : c->ncu; }
 static FusedShape fused_shape(fh_ctx* c) {
   if (c->op != OP_DENSE || c->prox_kind == FH_PROX_TVBALL) return FusedShape{0, 0, 0, 0, 0};
-  return fused_shape_for(c->n, c->ld, c->f32, c->fused_variant, c->ncu);
+  return fused_shape_for(c->n, c->ld, c->f32, c->fused_variant, fused_ncu(c));
 }
 static int fused_ppt(fh_ctx* c) { return fused_shape(c).ppt; }
 // diagnostic / test entry: the shape chosen for n columns and whether its kernel is instantiated (no device needed)
@@ -384,7 +387,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
   p.ldp = (uint32_t)(c->ld / (c->f32 ? 4 : 2));
   p.nv2 = p.ld2 * (c->f32 ? 2u : 1u);
-  p.nteams = (uint32_t)(c->ncu / sh.team);
+  p.nteams = (uint32_t)(fused_ncu(c) / sh.team);
   // few rows: fewer teams (at least FUSED_MIN_ROWS rows each when possible, and a multiple of 8 teams so that the members of
   // a team stay on one XCD): a smaller grid barrier and fewer g1 partials to sum in the epilogue
   if (c->fused_min_rows > 0) {
@@ -439,8 +442,8 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
 // z = A x, g = A^T grad f(z) from ONE read of A when the one-pass kernel pays off (single GPU, fused_pays()):
 // identity prox and tau = 0 make xprox = x.  `xhat` and the prox target serve as the launch's scratch outputs.
 // ---- co-residency probe ----------------------------------------------------------------------------------------------------
-// The one-pass dense kernel needs ONE WORKGROUP ON EVERY compute unit the device reports, all at the same time (teams exchange
-// partial sums while they run).  A CU mask, a partition mode or a co-tenant that hides CUs does not change the reported count, and
+// The one-pass dense kernel needs ONE WORKGROUP ON EVERY compute unit it is launched on -- all the device reports, or the
+// FH_TUNE_FUSED_CUS of them -- all at the same time (teams exchange partial sums while they run).  A CU mask, a partition mode or a co-tenant that hides CUs does not change the reported count, and
 // the kernel would run into its bounded spins (0.4-0.5 s) before the solver drops it.  k_coresident finds out in ~20 us instead:
 // it launches that many workgroups, each claiming more than half of a CU's LDS (so no two can share a CU), which count themselves
 // in and wait -- at most 2 ms -- for the count to reach the grid size.  If some of them cannot start until others have ended, the
@@ -474,12 +477,12 @@ static bool run_coresident_probe(fh_ctx* c, unsigned grid) {                    
   return host[1] == 0 && host[0] == grid;
 }
 static bool co_resident(fh_ctx* c) {
+  if (c->fused_variant & 128) return false;          // test hook (FH_TUNE_FUSED_VARIANT bit 128): "this rank's probe said no"
   if (c->coresident >= 0) return c->coresident != 0;
-  if (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) c->coresident = 0;       // known to hide CUs: no need to probe
-  else {                                             // (a second try: a transient co-tenant must not cost this context the one-pass kernel)
-    const unsigned grid = (unsigned)std::max(1, c->ncu);
-    c->coresident = (run_coresident_probe(c, grid) || run_coresident_probe(c, grid)) ? 1 : 0;
-  }
+  // (the probe decides, nothing else: no environment variable is consulted.  A second try: a transient co-tenant must not cost this
+  // context the one-pass kernel.)
+  const unsigned grid = (unsigned)std::max(1, fused_ncu(c));
+  c->coresident = (run_coresident_probe(c, grid) || run_coresident_probe(c, grid)) ? 1 : 0;
   return c->coresident != 0;
 }
 // diagnostic: can `workgroups` whole-CU workgroups run side by side on this context's device?  (ncu: yes on a healthy device;

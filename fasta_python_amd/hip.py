@@ -22,7 +22,7 @@ NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
- TUNE_TV_RING, TUNE_TV_SLOTS) = range(16)
+ TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS) = range(17)
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
 CREATE_RCCL_SHELL = 0x100          # or'ed into the dtype of fh_create_ex: the multi-device (RCCL) form even for a single device
@@ -71,6 +71,8 @@ SIGNATURES = {
     "fh_comm_init": (_i32, [_ctx, _i32, _i32, C.c_void_p]),
     "fh_comm_count": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_comm_destroy": (_i32, [_ctx]),
+    "fh_comm_library": (C.c_char_p, []),
+    "fh_cu_count": (_i32, [_ctx, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_timing_enable": (_i32, [_ctx, _i32]),
     "fh_timing_get": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
     "fh_timing_reset": (_i32, [_ctx]),
@@ -124,6 +126,12 @@ def device_count():
     return n.value
 
 
+def device_cus(device=0):
+    """Compute units device `device` reports (a throw-away context asks the runtime)."""
+    with HipContext(int(device)) as c:
+        return c.cu_count()[0]
+
+
 def fused_shape(n, storage="f64", variant=2, ncu=256):
     """((pieces per lane, posting distance, team members, x slice in LDS, row buffers), instantiated) of the one-pass kernel for
     rows of n columns; all zeros = no one-pass kernel for that width.  Host-only (works without a GPU)."""
@@ -132,6 +140,11 @@ def fused_shape(n, storage="f64", variant=2, ncu=256):
     inst = _i32(0)
     _check(lib, lib.fh_fused_shape(int(n), STORAGE[storage], int(variant), int(ncu), shape, C.byref(inst)))
     return tuple(shape), bool(inst.value)
+
+
+def comm_library():
+    """Path of the library the collectives come from ("" before the first communicator): the system's RCCL or $FASTA_RCCL_LIB."""
+    return load_library().fh_comm_library().decode(errors="replace")
 
 
 def comm_unique_id():
@@ -358,6 +371,12 @@ class HipContext:
     def comm_destroy(self):
         self._call("fh_comm_destroy")
         self.sharded = False
+
+    def cu_count(self):
+        """(CUs the device reports, CUs the dense one-pass kernel is launched on -- TUNE_FUSED_CUS)."""
+        dev, used = _i32(0), _i32(0)
+        self._call("fh_cu_count", C.byref(dev), C.byref(used))
+        return int(dev.value), int(used.value)
 
     # ---- measurement ----------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -91,7 +91,8 @@ enum fh_tuning_key {
   FH_TUNE_TV_NT = 8,         /* stencil kernels: 0 = default, 1 = non-temporal loads and stores (two-launch kernels and the z-streaming
                                 one-pass kernels; the z-free one-pass sweep never loads non-temporally: its halo columns and rows are
                                 re-read through L2), 2 = non-temporal stores (the z-free sweep's default), 3 = plain accesses      */
-  FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h)   */
+  FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h); bit 64 / 128: test hooks (a withheld
+                                team partial; this context's co-residency probe answers no)                                    */
   FH_TUNE_TV_ZFREE = 10,     /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
                                 pixel); 0 = the round-1 kernels that stream z (56 / 80 B per pixel)                          */
   FH_TUNE_TV_PIPE = 11,      /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 = three rotating
@@ -103,9 +104,13 @@ enum fh_tuning_key {
   FH_TUNE_TV_RING = 14,      /* z-free one-pass stencil sweep: 2 or 3 = trips prefetched by LDS-DMA into a per-wave ring of that many
                                 2-row slots (loads in flight cost no registers); 1 = register-staged trips (FH_TUNE_TV_PIPE);
                                 0 = auto.  Needs an even image width, otherwise the register form runs                        */
-  FH_TUNE_TV_SLOTS = 15      /* z-free one-pass stencil sweep, persistent form: launch at most this many workgroups per CU (1..8); each
+  FH_TUNE_TV_SLOTS = 15,     /* z-free one-pass stencil sweep, persistent form: launch at most this many workgroups per CU (1..8); each
                                 walks the chunk ids (FH_TUNE_TV_ROWS rows each, band-major) with the grid as its stride, so that the
                                 resident workgroups sweep the image as one compact moving window; 0 = one workgroup per chunk     */
+  FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
+                                reports).  The co-residency probe then asks for that many.  Lets several one-pass grids run side by side
+                                on one device: two solves at once, partitioned devices, ranks of a row-sharded run that share a GPU
+                                (the tests: world x (CUs / world)).  The team shape needs a multiple of the team size (<= 32)        */
 };
 
 /* ---- library / context -------------------------------------------------------------- */
@@ -233,6 +238,11 @@ int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
 /* ranks of the attached communicator as RCCL reports them (ncclCommCount); 1 without a communicator */
 int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
+/* path of the library the collectives' entry points were taken from: the system's RCCL, or what $FASTA_RCCL_LIB names (a
+ * substitution is also announced once on stderr); "" before the first communicator                                         */
+const char* fh_comm_library(void);
+/* CUs the device reports, and CUs the dense one-pass kernel is launched on (FH_TUNE_FUSED_CUS)                               */
+int fh_cu_count(fh_ctx* ctx, int* device_cus, int* one_pass_cus);
 
 /* ---- measurement: HIP-event timing of each launch on the context's stream --------------------- */
 int fh_timing_enable(fh_ctx* ctx, int on);

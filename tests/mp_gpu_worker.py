@@ -18,6 +18,7 @@ from fasta_python_amd import hip                # noqa: E402
 
 def main():
     out_dir, mode, m, n, fused = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    probe_no_rank = int(sys.argv[6]) if len(sys.argv) > 6 else -1     # this rank's co-residency probe is made to answer "no"
     grp = bench.make_group(120.0)
     rng = np.random.RandomState(7)              # the same problem on every rank
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -27,6 +28,12 @@ def main():
     lo = grp.rank * m // grp.world
     hi = (grp.rank + 1) * m // grp.world
     op = fa.DenseMatrixMap(np.ascontiguousarray(A[lo:hi]), device=0)
+    # The ranks SHARE this GPU, and a one-pass launch needs all of its workgroups resident at once: each rank takes its share of the
+    # CUs (world x (CUs / world) whole-CU workgroups are co-resident by construction), so the one-pass kernel must serve every launch.
+    dev_cus, _ = op.ctx.cu_count()
+    op.ctx.set_tuning(hip.TUNE_FUSED_CUS, max(32, dev_cus // grp.world // 32 * 32))
+    if grp.rank == probe_no_rank:
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 128)
     uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
     op.ctx.comm_init(grp.world, grp.rank, uid)
     assert op.ctx.comm_count() == grp.world and op.ctx.sharded
@@ -37,14 +44,27 @@ def main():
     if mode == "forced_backtracking":
         opts.update(L=1.0, tau0=5000.0)
     np.random.seed(9)                           # same Lipschitz probes on every rank
+    raised = ""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        solver = fa.FBSolver(op, ls, reg, np.zeros(n), **opts).setup()
-        c = solver.run()
-    comm_ms, comm_launches = op.ctx.timing_get(hip.K_COMM)
-    np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), residuals=c.residuals, stepsizes=c.stepsizes, objectives=c.objectives,
-             iterates=c.iterates, solution=c.solution, iteration_count=c.iteration_count, backtracks=c.backtracks,
-             fused_steps=solver.fused_steps, use_fused=int(solver.use_fused))
+        try:
+            solver = fa.FBSolver(op, ls, reg, np.zeros(n), **opts).setup()
+        except ValueError as exc:                  # fused=True without a one-pass kernel: must happen on EVERY rank or on none
+            raised = str(exc)
+    if raised:
+        np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), raised=raised)
+    else:
+        op.ctx.timing_reset()
+        op.ctx.timing_enable(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = solver.run()
+        comm_ms, comm_launches = op.ctx.timing_get(hip.K_COMM)      # exchanges of the loop alone
+        np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), residuals=c.residuals, stepsizes=c.stepsizes, objectives=c.objectives,
+                 iterates=c.iterates, solution=c.solution, iteration_count=c.iteration_count, backtracks=c.backtracks,
+                 fused_steps=solver.fused_steps, use_fused=int(solver.use_fused), solver_mode=str(solver.mode),
+                 backoff=solver._fused_backoff, comm_launches=int(comm_launches), cus=np.array(op.ctx.cu_count()),
+                 comm_library=hip.comm_library())
     grp.barrier()
     op.ctx.comm_destroy()
     op.close()

@@ -347,14 +347,15 @@ def test_setup_passes_use_the_one_pass_kernel_at_large_n():
 
 
 def test_coresidency_probe_says_yes_for_the_cus_and_no_beyond():
-    """fh_fused_supported no longer sniffs environment variables for hidden CUs: a probe launch of one whole-CU workgroup per
+    """fh_fused_supported consults no environment variable for hidden CUs: a probe launch of one whole-CU workgroup per
     reported CU must see all of them running at once.  One workgroup MORE can never be co-resident: the probe must say so, quickly."""
     import time
     op = fa.DenseMatrixMap(np.ones((64, 20000)))
     try:
         c = op.ctx
         assert c.fused_supported() == 1                     # probes on first use
-        ncu = 256
+        ncu, used = c.cu_count()                            # read from the device, not assumed
+        assert used == ncu and ncu >= 8
         assert c.coresident_probe(ncu)
         t0 = time.time()
         assert not c.coresident_probe(ncu + 1)
@@ -364,3 +365,42 @@ def test_coresidency_probe_says_yes_for_the_cus_and_no_beyond():
         assert np.isfinite(s).all()
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("m,n,cus", [(300, 4096, 128), (200, 16384, 64), (70, 65536, 128), (40, 131072, 32), (130, 32768, 96), (23, 108000, 64)])
+def test_one_pass_kernel_on_a_capped_number_of_cus(m, n, cus):
+    """FH_TUNE_FUSED_CUS: the one-pass launch (and its co-residency probe) on `cus` workgroups instead of one per CU of the device --
+    what lets two one-pass grids share a device.  Same iterates and sums to rounding (the number of teams, hence the summation order, changes), plain and accelerated; and TWO contexts whose
+    caps add up to the device run their launches CONCURRENTLY on two streams without timing each other out."""
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b, x0 = rng.randn(m), rng.randn(n) * 0.05
+    tau, mu = 0.4, 0.03
+    op = fa.DenseMatrixMap(A)
+    op2 = fa.DenseMatrixMap(A, tuning={hip.TUNE_FUSED_CUS: cus})
+    try:
+        ref = _state(op, b, mu, x0)
+        f0 = ref.step(tau)
+        xp0, g0 = ref.get_vector(hip.VEC_XPROX, n), ref.get_vector(hip.VEC_G1, n)
+        c = _state(op2, b, mu, x0)
+        assert c.cu_count() == (ref.cu_count()[0], cus) and c.fused_supported() in (1, 3)
+        f1 = c.step(tau)
+        # (not bit-equal: g0 = A^T(A x0 - b) of fh_init is itself summed over another number of teams)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_XPROX, n), xp0, rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G1, n), g0, rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(f1[:15], f0[:15], rtol=1e-10, atol=1e-18)
+        c.commit(False)
+        ref.commit(False)
+        a0, a1 = ref.step_accel(tau, 0.3, True), c.step_accel(tau, 0.3, True)
+        np.testing.assert_allclose(a1[:15], a0[:15], rtol=1e-10, atol=1e-18)
+        # two capped contexts, launches in flight at the same time (each context has its own stream; step() syncs only its own)
+        total = ref.cu_count()[0]
+        if 2 * cus <= total:
+            op.ctx.set_tuning(hip.TUNE_FUSED_CUS, cus)
+            ra, rb = _state(op, b, mu, x0), _state(op2, b, mu, x0)
+            for _ in range(20):
+                sa, sb = ra.step(tau), rb.step(tau)                   # a HipTimeout here would fail the test
+                assert np.array_equal(sa, sb)                         # same cap, same shape: same bits
+    finally:
+        op.close()
+        op2.close()

@@ -439,3 +439,48 @@ def test_tv_adaptive_runs_to_convergence_and_the_first_divergence_from_the_oracl
     fg, fw = got.objectives[got.iteration_count], want.objectives[want.iteration_count]
     assert abs(fg - fw) <= 1e-3 * abs(fw)
     np.testing.assert_allclose(pr.tv_primal(M, mu, got.solution), pr.tv_primal(M, mu, want.solution), atol=2e-2)
+
+
+@pytest.mark.parametrize("ring,slots,rows", [(2, 0, 0), (3, 0, 0), (1, 2, 16), (2, 3, 8), (1, 1, 4), (2, 5, 32)])
+@pytest.mark.parametrize("H_,W_", [(2, 4), (5, 64), (33, 62), (40, 258), (97, 130), (64, 1000), (130, 122), (300, 4000), (37, 61)])
+def test_ring_and_persistent_forms_of_the_one_pass_sweep_equal_the_default(H_, W_, ring, slots, rows):
+    """Round 4: FH_TUNE_TV_RING (2-row trips prefetched by LDS-DMA into a per-wave ring; needs an even width -- an odd one runs the
+    register form) and FH_TUNE_TV_SLOTS (persistent workgroups walking short chunks) change how the sweep's bytes arrive and which
+    workgroup sums what, never a stored value: xprox must be BIT-identical to the default sweep's, the sums equal to rounding -- plain
+    and accelerated steps, with and without a lagging extrapolation coefficient."""
+    rng = np.random.RandomState(H_ * 11 + W_)
+    M = rng.randn(H_, W_)
+    Y0 = rng.randn(H_, W_, 2) * 0.8
+    tau = 0.11
+    op = fa.GradDivMap((H_, W_))
+    try:
+        c = op.ctx
+
+        def signature():
+            c.set_loss_lsq(M)
+            c.set_prox(hip.PROX_TVBALL)
+            c.set_vector(hip.VEC_X0, Y0)
+            c.init()
+            s = c.step(tau)
+            xp = c.get_vector(hip.VEC_XPROX, Y0.size)
+            c.set_vector(hip.VEC_X0, Y0)
+            c.init()
+            a1 = c.step_accel(tau, 0.0, True)
+            c.commit(False)
+            a2 = c.step_accel(tau, 0.3, False)          # reads both prox outputs (lagging coefficient of the previous step)
+            c.commit(False)
+            a3 = c.step_accel(tau, 0.45, True)
+            xa = c.get_vector(hip.VEC_XPROX, Y0.size)
+            return s, xp, a1, a2, a3, xa
+        for key, v in ((hip.TUNE_TV_RING, 1), (hip.TUNE_TV_SLOTS, 0), (hip.TUNE_TV_ROWS, 0)):
+            c.set_tuning(key, v)
+        ref = signature()
+        for key, v in ((hip.TUNE_TV_RING, ring), (hip.TUNE_TV_SLOTS, slots), (hip.TUNE_TV_ROWS, rows)):
+            c.set_tuning(key, v)
+        got = signature()
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[5], ref[5])
+        for g, r in ((got[0], ref[0]), (got[2], ref[2]), (got[3], ref[3]), (got[4], ref[4])):
+            np.testing.assert_allclose(g, r, rtol=1e-11, atol=1e-300)
+        assert np.array_equal(signature()[0], got[0])                 # and the chosen form is bitwise repeatable
+    finally:
+        op.close()
