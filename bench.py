@@ -50,6 +50,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the headline's timed region (a fresh solve: setup, W warm-up steps, K timed steps) is run "
+                    "this many times; value = the median run, the spread is reported (SURVEY.md 8(d): median of >= 5 runs)")
+    ap.add_argument("--extra-repeats", type=int, default=3, help="repeats of every sub-result's timed region")
     ap.add_argument("--rows", dest="m", type=int, default=65536, help="total rows of A (default: BASELINE config 2)")
     ap.add_argument("--cols", dest="n", type=int, default=65536)
     ap.add_argument("--workload", default="lasso", choices=["lasso", "nnls", "tv"],
@@ -78,7 +81,10 @@ def parse(argv=None):
     ap.add_argument("--launcher", default="auto", choices=["auto", "torch", "socket"],
                     help="how `--gpus N` from a bare shell starts its workers: torch.distributed.run, or the built-in spawner with the "
                          "TCP rendezvous (auto: torch when importable)")
+    ap.add_argument("--job-timeout", type=float, default=3000.0, help="own spawner: wall-clock limit of the whole N-rank job; the ranks are ended "
+                    "and the exit status is non-zero when it passes (a rank stuck in a GPU collective is not covered by --rdv-timeout)")
     ap.add_argument("--rdv-timeout", type=float, default=600.0, help="seconds any rendezvous wait may take before the job is abandoned")
+    ap.add_argument("--hang-at-rank", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank sleeps forever after the first barrier
     ap.add_argument("--die-at-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank exits(3) after the first barrier
     return ap.parse_args(argv)
 
@@ -121,15 +127,26 @@ def self_launch(args, argv):
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
         return subprocess.run(cmd, env=_worker_env()).returncode
     port = _free_port()
+    token = os.urandom(16).hex()                       # the ranks prove they belong to THIS job (the port is open to every local user)
     procs = []
     for rank in range(args.gpus):
         env = _worker_env({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus),
-                           "FASTA_BENCH_RDV": f"127.0.0.1:{port}"})
+                           "FASTA_BENCH_RDV": f"127.0.0.1:{port}", "FASTA_BENCH_TOKEN": token})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     pending = list(procs)
+    deadline = time.time() + args.job_timeout          # a rank stuck inside a GPU collective is not covered by the rendezvous timeouts
     while pending:
         time.sleep(0.05)
+        if time.time() > deadline:
+            print(f"bench.py: the job exceeded --job-timeout {args.job_timeout:.0f} s; ending its {len(pending)} remaining rank(s)", file=sys.stderr)
+            for other in pending:
+                other.terminate()
+            time.sleep(2.0)
+            for other in pending:
+                if other.poll() is None:
+                    other.kill()
+            return rc or 124
         for pr in list(pending):
             code = pr.poll()
             if code is None:
@@ -159,26 +176,41 @@ class quiet_stdout:
 
 class SocketGroup:
     """Dependency-free rendezvous for the ranks of one node: rank 0 listens on FASTA_BENCH_RDV, the others connect; barrier,
-    byte broadcast and max-reduce are one round trip through rank 0.  Every wait is bounded by `timeout` seconds."""
+    byte broadcast and max-reduce are one round trip through rank 0.  Every wait is bounded by `timeout` seconds.
+    Wire format: fixed binary frames -- [kind: 1 byte][length: 8 bytes little endian][payload] with kind N (nothing), F (one float64),
+    B (raw bytes) -- nothing that is received is ever unpickled or evaluated.  A connecting peer first sends a hello frame (the job's
+    token from FASTA_BENCH_TOKEN, then its rank as 4 bytes); rank 0 drops connections whose token is not this job's."""
+    MAX_FRAME = 1 << 20
 
     def __init__(self, rank, world, addr, timeout):
-        import pickle
-        self.pickle = pickle
+        import hmac
         self.rank, self.world, self.local_rank = rank, world, int(os.environ.get("LOCAL_RANK", rank))
         self.force, self.dist = False, self
+        self.token = os.environ.get("FASTA_BENCH_TOKEN", "").encode()
         host, port = addr.rsplit(":", 1)
         self.peers = []
         if rank == 0:
             srv = socket.socket()
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((host, int(port)))
-            srv.listen(world)
-            srv.settimeout(timeout)
+            srv.listen(world + 4)
+            deadline = time.time() + timeout
             by_rank = {}
-            for _ in range(world - 1):
-                conn, _ = srv.accept()
+            while len(by_rank) < world - 1:
+                srv.settimeout(max(0.05, deadline - time.time()))
+                conn, _ = srv.accept()                  # socket.timeout after `timeout` seconds in all
+                conn.settimeout(min(timeout, 10.0))
+                try:
+                    hello = self._recv(conn)
+                    ok = (isinstance(hello, bytes) and len(hello) == len(self.token) + 4 and hmac.compare_digest(hello[:-4], self.token))
+                    peer = int.from_bytes(hello[-4:], "little") if ok else -1
+                    if not (1 <= peer < world) or peer in by_rank:
+                        raise ConnectionError("not a rank of this job")
+                except (OSError, ValueError, ConnectionError):
+                    conn.close()                        # a stranger (or a duplicate): ignored, the job goes on waiting for its ranks
+                    continue
                 conn.settimeout(timeout)
-                by_rank[self._recv(conn)] = conn
+                by_rank[peer] = conn
             srv.close()
             self.peers = [by_rank[r] for r in range(1, world)]
         else:
@@ -192,13 +224,23 @@ class SocketGroup:
                         raise
                     time.sleep(0.05)
             self.conn.settimeout(timeout)
-            self._send(self.conn, rank)
+            self._send(self.conn, self.token + int(rank).to_bytes(4, "little"))
 
-    def _send(self, conn, obj):
-        data = self.pickle.dumps(obj)
-        conn.sendall(len(data).to_bytes(8, "little") + data)
+    @staticmethod
+    def _send(conn, obj):
+        import struct
+        if obj is None:
+            kind, data = b"N", b""
+        elif isinstance(obj, (bytes, bytearray)):
+            kind, data = b"B", bytes(obj)
+        else:
+            kind, data = b"F", struct.pack("<d", float(obj))
+        conn.sendall(kind + len(data).to_bytes(8, "little") + data)
 
-    def _recv(self, conn):
+    @classmethod
+    def _recv(cls, conn):
+        import struct
+
         def exact(k):
             buf = b""
             while len(buf) < k:
@@ -207,7 +249,12 @@ class SocketGroup:
                     raise ConnectionError("a rank closed its rendezvous connection (it died?)")
                 buf += chunk
             return buf
-        return self.pickle.loads(exact(int.from_bytes(exact(8), "little")))
+        head = exact(9)
+        kind, size = head[:1], int.from_bytes(head[1:], "little")
+        if size > cls.MAX_FRAME or kind not in (b"N", b"B", b"F") or (kind == b"F" and size != 8) or (kind == b"N" and size):
+            raise ValueError("malformed rendezvous frame")
+        data = exact(size)
+        return None if kind == b"N" else (data if kind == b"B" else struct.unpack("<d", data)[0])
 
     def _gather_scatter(self, value, combine):
         """rank 0 collects one value per rank, combines, sends the result back"""
@@ -294,6 +341,8 @@ def plumbing_only(args, grp):
     grp.barrier()
     if args.die_at_rank == grp.rank:                       # tests: a rank that dies mid-job must end the job, not hang it
         os._exit(3)
+    if args.hang_at_rank == grp.rank:                      # tests: a rank stuck for good (as inside a GPU collective): --job-timeout ends the job
+        time.sleep(1e6)
     t0 = time.perf_counter()
     time.sleep(0.01 * (grp.rank + 1))
     grp.barrier()
@@ -372,30 +421,57 @@ def pmc_traffic(kernel_substr):
 # ------------------------------------------------------------------------------------------------------------
 # timed loops
 # ------------------------------------------------------------------------------------------------------------
-def timed_steps(solver, ctx, grp, warmup, steps):
-    """W untimed + exactly K timed solver steps between barrier + device sync on both sides; max over ranks."""
+def timed_steps(make_solver, ctx, grp, warmup, steps, repeats=1, trace=False):
+    """`repeats` runs of: a fresh solve (make_solver().setup()), W untimed steps, exactly K timed steps between barrier + device sync on
+    both sides (max over ranks).  Returns the MEDIAN run (its wall clock, its HIP-event kernel times, its backtracks) with the spread
+    over the runs next to it -- the first run separately, so that a cold start (first touch of a fresh buffer, clocks) is visible and
+    not averaged in -- mirroring the reference's harness, which runs every mode and reads the times off each run
+    (fasta/examples/__init__.py:54-91).  trace: wall time of every step of the first run, warm-up included."""
     import numpy as np
     from fasta_python_amd import hip
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        solver.setup()
-        for _ in range(warmup):
-            solver.step()
-        ctx.timing_reset()
-        ctx.timing_enable(True)
-        bt0 = solver.total_backtracks
-        fs0 = solver.fused_steps
-        grp.barrier(); ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            solver.step()
-        ctx.sync(); grp.barrier()
-        t1 = time.perf_counter()
-        ctx.timing_enable(False)
-    elapsed = grp.max(t1 - t0)
-    k = {name: ctx.timing_get(kid) for name, kid in
-         (("fwd", hip.K_FWD), ("adj", hip.K_ADJ), ("comm", hip.K_COMM), ("fused", hip.K_FUSED), ("aux", hip.K_AUX))}
-    return {"elapsed": elapsed, "backtracks": solver.total_backtracks - bt0, "fused_steps": solver.fused_steps - fs0, "k": k}
+    runs = []
+    for rep in range(max(1, repeats)):
+        solver = make_solver()
+        step_ms = []
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            solver.setup()
+            for _ in range(warmup):
+                ts = time.perf_counter()
+                solver.step()
+                step_ms.append((time.perf_counter() - ts) * 1e3)
+            ctx.timing_reset()
+            ctx.timing_enable(True)
+            bt0 = solver.total_backtracks
+            fs0 = solver.fused_steps
+            grp.barrier(); ctx.sync()
+            t0 = time.perf_counter()
+            if trace and rep == 0:
+                for _ in range(steps):
+                    ts = time.perf_counter()
+                    solver.step()
+                    step_ms.append((time.perf_counter() - ts) * 1e3)
+            else:
+                for _ in range(steps):
+                    solver.step()
+            ctx.sync(); grp.barrier()
+            t1 = time.perf_counter()
+            ctx.timing_enable(False)
+        elapsed = grp.max(t1 - t0)
+        k = {name: ctx.timing_get(kid) for name, kid in
+             (("fwd", hip.K_FWD), ("adj", hip.K_ADJ), ("comm", hip.K_COMM), ("fused", hip.K_FUSED), ("aux", hip.K_AUX))}
+        runs.append({"elapsed": elapsed, "backtracks": solver.total_backtracks - bt0, "fused_steps": solver.fused_steps - fs0, "k": k,
+                     "solver": solver, "step_ms": step_ms})
+    order = sorted(range(len(runs)), key=lambda i: runs[i]["elapsed"])
+    med = runs[order[len(order) // 2]]
+    per_step = [r["elapsed"] / steps * 1e3 for r in runs]
+    med["spread"] = {"repeats": len(runs), "ms_per_step": {"first": per_step[0], "min": min(per_step), "median": med["elapsed"] / steps * 1e3,
+                                                            "max": max(per_step)},
+                     "runs_ms_per_step": per_step, "backtracks_per_run": [r["backtracks"] for r in runs]}
+    if trace:
+        med["spread"]["first_run_step_ms"] = [round(v, 4) for v in runs[0]["step_ms"]]
+        med["spread"]["first_run_step_ms_note"] = f"wall time of each step of the first run: {warmup} warm-up steps, then the {steps} timed ones"
+    return med
 
 
 def kernel_table(per):
@@ -415,7 +491,7 @@ def dense_bytes(m, n, esize=8):
             "fused": m * n * esize + (3 * m + 7 * n) * 8}
 
 
-def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False, plain=False):
+def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelerate=False, plain=False, repeats=None, trace=False):
     """One dense workload (LASSO or NNLS) on the resident matrix `A` (this rank's row block); the three modes of the reference's
     test_modes (examples/__init__.py:66-91): adaptive (default), accelerated (FISTA), plain (neither)."""
     import numpy as np
@@ -430,10 +506,12 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
     loss = fa.LeastSquares(b)
     reg = fa.Shrink(mu) if workload == "lasso" else fa.NonNeg()
-    solver = fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not (accelerate or plain), accelerate=accelerate, verbose=False,
-                         max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
-    np.random.seed(3)           # same Lipschitz probes on every rank
-    t = timed_steps(solver, ctx, grp, warmup, steps)
+    def make_solver():
+        np.random.seed(3)       # same Lipschitz probes on every rank, in every repeat
+        return fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not (accelerate or plain), accelerate=accelerate, verbose=False,
+                           max_iters=warmup + steps, tolerance=0.0, backtrack=True, evaluate_objective=False, fused=fused)
+    t = timed_steps(make_solver, ctx, grp, warmup, steps, args.extra_repeats if repeats is None else repeats, trace)
+    solver = t["solver"]
     # per LAUNCH: a multi-device context launches once per row block (its timers add up launches and time over the blocks)
     by = dense_bytes(m_local // blocks, n, 4 if getattr(A, "storage", "f64") == "f32" else 8)
     per = {"fasta_fwd(k_fwd_dense)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_dense)": t["k"]["adj"] + (by["adj"],),
@@ -452,7 +530,7 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
                               "note": "SURVEY.md 8(d) byte model (A read twice per iteration) / wall-clock: exceeds the spec peak "
                                       "when the one-pass kernel reads A once"},
         "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None, "comm_launches": comm_cnt,
-        "solver": solver, "b": b, "mu": mu,
+        "solver": solver, "b": b, "mu": mu, "spread": t["spread"],
     }
 
 
@@ -489,7 +567,7 @@ def sub_result(r, workload):
     return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
             "backtracks_in_timed_steps": r["backtracks"], "kernel": r["dominant"], "avg_launch_ms": d.get("avg_ms"),
             "achieved_GB/s": d.get("GB/s"), "frac": d.get("GB/s") / HBM_PEAK_GBS if d else None,
-            "per_kernel": r["per_kernel"]}
+            "per_kernel": r["per_kernel"], "spread": r.get("spread")}
 
 
 def tv_bytes(P, accelerate, zfree=True):
@@ -507,7 +585,7 @@ def tv_kernel_name(accelerate, zfree):
     return "fasta_step_accel(k_fused_tv_accel)" if accelerate else "fasta_step(k_fused_tv_step)"
 
 
-def run_tv(args, grp, steps, warmup, fused, accelerate):
+def run_tv(args, grp, steps, warmup, fused, accelerate, repeats=3):
     """BASELINE config 4: TV denoising dual on an image of side --image, 1 GPU."""
     import numpy as np
     import fasta_python_amd as fa
@@ -526,10 +604,11 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
             zfree = bool(int(v))
     try:
         loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
-        solver = fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=not accelerate, accelerate=accelerate,
-                             verbose=False, max_iters=warmup + steps, tolerance=0.0, fused=fused)
-        np.random.seed(3)
-        t = timed_steps(solver, A.ctx, grp, warmup, steps)
+        def make_solver():
+            np.random.seed(3)
+            return fa.FBSolver(A, loss, reg, np.zeros(M.shape + (2,)), adaptive=not accelerate, accelerate=accelerate,
+                               verbose=False, max_iters=warmup + steps, tolerance=0.0, fused=fused)
+        t = timed_steps(make_solver, A.ctx, grp, warmup, steps, repeats)
     finally:
         A.close()
     P = side * side
@@ -548,7 +627,7 @@ def run_tv(args, grp, steps, warmup, fused, accelerate):
         "vs_materialised_model": {"bytes_per_iteration": 136 * P, "GB/s": model_bytes / t["elapsed"] / 1e9,
                                   "frac": model_bytes / t["elapsed"] / 1e9 / HBM_PEAK_GBS,
                                   "note": "SURVEY.md 8(d) materialised-vector model (136*P per iteration + 64*P per backtrack) / wall-clock"},
-        "side": side,
+        "side": side, "spread": t["spread"],
     }
 
 
@@ -559,7 +638,7 @@ def tv_line(args, r, accelerate):
         "metric": "FBS iterations/sec, TV denoising dual (div/grad stencil, unit-ball prox)",
         "value": r["value"], "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "spread": r["spread"],
         "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), {'FISTA' if accelerate else 'adaptive FBS'} with backtracking",
                    "backtracks_in_timed_steps": r["backtracks"], "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GB/s"] / HBM_PEAK_GBS,
@@ -598,7 +677,7 @@ def main(argv=None):
     if args.workload == "tv":
         if grp.world != 1:
             raise SystemExit("the TV workload is single-GPU (BASELINE config 4)")
-        print(json.dumps(tv_line(args, run_tv(args, grp, args.steps, args.warmup, fused, args.accelerate), args.accelerate)))
+        print(json.dumps(tv_line(args, run_tv(args, grp, args.steps, args.warmup, fused, args.accelerate, args.repeats), args.accelerate)))
         return grp.close()
 
     m_total, n = args.m, args.n
@@ -639,7 +718,7 @@ def main(argv=None):
     want_ranks = args.gpus if (args.inproc or grp.world > 1) else 1
     if ranks_seen != want_ranks:
         raise SystemExit(f"row sharding over {want_ranks} GPUs was asked for but the communicator reports {ranks_seen} rank(s)")
-    main_r = run_dense(args, grp, A, m_total, n, args.workload, fused, args.steps, args.warmup, args.accelerate)
+    main_r = run_dense(args, grp, A, m_total, n, args.workload, fused, args.steps, args.warmup, args.accelerate, repeats=args.repeats)
     dom = main_r["dominant"]
     d = main_r["per_kernel"][dom]
     traffic, traffic_src = (pmc_traffic("k_fused_dense" if "fused" in dom else ("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>"))
@@ -664,6 +743,9 @@ def main(argv=None):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": main_r["ms_per_step"],
+        "spread": main_r["spread"],
+        "protocol": (f"value = the MEDIAN of {args.repeats} runs of the timed region; each run is a fresh solve: setup, {args.warmup} untimed steps, exactly "
+                     f"{args.steps} timed steps between barrier + device sync on both sides; spread.ms_per_step gives first / min / median / max"),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -734,7 +816,9 @@ def main(argv=None):
             if (m_total, n) == (65536, 65536):
                 Aw = fa.DenseMatrixMap.synthetic(32768, 131072, seed=0, scale=synthetic.lasso_scale(32768, 131072), device=grp.local_rank)
                 try:
-                    r = run_dense(args, grp, Aw, 32768, 131072, "lasso", fused, args.steps, args.warmup)
+                    # (the driver's round-3 line had this sub-result at 5.28 ms / launch against 4.78-4.88 in five builder runs, one sample
+                    # each: now `extra_repeats` fresh solves, the first reported separately, and every step of the first run traced)
+                    r = run_dense(args, grp, Aw, 32768, 131072, "lasso", fused, args.steps, args.warmup, trace=True)
                     s = sub_result(r, "LASSO 32768x131072 float64 (wide rows: 16 members x 16 pieces, x slice in LDS)")
                     s["fused_supported"] = Aw.ctx.fused_supported()
                     extra["lasso_wide_131072"] = s
@@ -743,7 +827,7 @@ def main(argv=None):
             # TV: warmed up INTO the backtracking regime (the adaptive run starts backtracking after ~40 iterations and then does so
             # every second or third one) and timed over 100 iterations, whatever --steps / --warmup say
             for key, acc in (("tv", False), ("tv_accelerated", True)):
-                r = run_tv(args, grp, max(args.steps, 100), max(args.warmup, 60), "auto", acc)
+                r = run_tv(args, grp, max(args.steps, 100), max(args.warmup, 60), "auto", acc, args.extra_repeats)
                 s = sub_result(r, f"TV denoising {args.image}x{args.image} (BASELINE config 4), "
                                   f"{'FISTA (test_modes accelerated)' if acc else 'adaptive FBS'}")
                 s["steps"], s["warmup"] = r["steps"], r["warmup"]

@@ -2,6 +2,7 @@
 // or a shell over one shard per device), buffer management, HIP-event timing, the scalar block's way back to the host and the
 // sums over row blocks.  Included by fasta_hip.hip only (one translation unit); the C ABI itself is in fasta_hip.hip.
 #pragma once
+#include <chrono>
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -177,9 +178,13 @@ struct fh_ctx {
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
-  bool ev_pending[FH_NKERNELS] = {false, false, false, false, false};
-  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0, 0};
-  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0, 0};
+  bool ev_pending[FH_NKERNELS] = {false, false, false, false, false, false};
+  // FH_K_HOST_ISSUE: host time of a one-pass dense step from its entry to the start of its final synchronisation
+  bool timing_skip_kernels = false;
+  double host_issue_ms = 0.0; uint64_t host_issue_calls = 0;
+  std::chrono::steady_clock::time_point issue_t0; bool issue_open = false;
+  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0, 0, 0};
+  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0, 0, 0};
   // comm
   fh_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
@@ -272,11 +277,12 @@ static int ensure_ws(fh_ctx* c, size_t bytes) {
 }
 
 // ---- timing helpers ------------------------------------------------------------------------------
+// (timing_skip_kernels: a block of a same-device multi-block context that is not the sampled one -- fh_timing_enable)
 static inline void t_begin(fh_ctx* c, int k) {
-  if (c->timing) { (void)hipEventRecord(c->ev[k][0], c->stream); }
+  if (c->timing && !(c->timing_skip_kernels && k != FH_K_COMM)) { (void)hipEventRecord(c->ev[k][0], c->stream); }
 }
 static inline void t_end(fh_ctx* c, int k) {
-  if (c->timing) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
+  if (c->timing && !(c->timing_skip_kernels && k != FH_K_COMM)) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
 }
 static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending event pairs
   if (!c->shards.empty()) {        // shell: all shards (an emulated group shares one stream; its first shard's sync covers the rest)
@@ -317,6 +323,11 @@ static int fetch_scalars(fh_ctx* c, double* scalars) {
       k_forward_scalars<<<dim3(1), dim3(64), 0, s->stream>>>(s->dscal, s->hscal_dev);
       HIP_TRY(hipGetLastError());
     }
+  }
+  if (c->issue_open) {             // everything of this call has been issued: what follows is the wait
+    c->host_issue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->issue_t0).count();
+    c->host_issue_calls += 1;
+    c->issue_open = false;
   }
   FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
   // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors

@@ -19,7 +19,7 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 (S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, S_GSUM, S_GMAX, S_RDOT, S_DXDG, S_DG2, S_FSQ_ADJ, S_XH2_ADJ,
  S_GSUM_ADJ, S_GMAX_ADJ, S_ALPHA) = range(15)
 NSCALARS = 16
-K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED = range(5)
+K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED, K_HOST_ISSUE = range(6)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
  TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS) = range(17)

@@ -77,7 +77,10 @@ enum fh_scalar {
   FH_NSCALARS = 16
 };
 
-enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_K_FUSED = 4, FH_NKERNELS = 5 };
+/* FH_K_HOST_ISSUE is not a kernel: fh_timing_get reports under it the HOST time a one-pass step of the dense operator (fh_step /
+ * fh_step_accel) spends issuing its launches and exchanges -- from the call's entry to the start of its one final synchronisation --
+ * and the number of such calls: what one host thread pays to drive all the row blocks of a multi-device context per iteration.   */
+enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_K_FUSED = 4, FH_K_HOST_ISSUE = 5, FH_NKERNELS = 6 };
 
 enum fh_tuning_key {
   FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8, 16 (0 = auto)        */
@@ -244,7 +247,10 @@ const char* fh_comm_library(void);
 /* CUs the device reports, and CUs the dense one-pass kernel is launched on (FH_TUNE_FUSED_CUS)                               */
 int fh_cu_count(fh_ctx* ctx, int* device_cus, int* one_pass_cus);
 
-/* ---- measurement: HIP-event timing of each launch on the context's stream --------------------- */
+/* ---- measurement: HIP-event timing of each launch on the context's stream ---------------------
+ * A multi-device context reports sums over its row blocks.  When the blocks share ONE device (a repeated device id: one stream) only
+ * the first block's launches carry event records and the figures are that block's scaled by the number of blocks -- two records
+ * around each of the 8 x 2 launches cost more than the plumbing being measured (profiles/r04_inproc_issue.txt).                   */
 int fh_timing_enable(fh_ctx* ctx, int on);
 int fh_timing_get(fh_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
 int fh_timing_reset(fh_ctx* ctx);

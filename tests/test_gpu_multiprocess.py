@@ -47,7 +47,7 @@ def _run_ranks(world, args, mock, timeout=300):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), FASTA_BENCH_RDV=f"127.0.0.1:{port}",
-                   FASTA_RCCL_LIB=mock, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+                   FASTA_BENCH_TOKEN=f"{port:032x}", FASTA_RCCL_LIB=mock, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_gpu_worker.py")] + [str(a) for a in args],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=timeout) for p in procs]

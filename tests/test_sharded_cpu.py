@@ -159,3 +159,72 @@ def test_row_partition_of_bench_covers_matrix_once():
         rows = [(r * (m_total // world), m_total // world) for r in range(world)]
         assert sum(c for _, c in rows) == m_total
         assert [s for s, _ in rows] == list(range(0, m_total, m_total // world))
+
+
+def test_socket_rendezvous_ignores_strangers_and_never_unpickles(tmp_path):
+    """rank 0 of bench.py's TCP rendezvous used to unpickle whatever the first connections sent.  The frames are now fixed
+    binary (kind, length, raw bytes / one float64) behind a per-job token: a stranger that connects first and sends a pickle that would
+    create a file is dropped -- nothing it sent is evaluated -- and the job completes with its own ranks."""
+    import pickle
+    import socket
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    port = _free_port()
+    marker = tmp_path / "owned"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+    payload = pickle.dumps(Evil())
+
+    def stranger():
+        deadline = time.time() + 20
+        while time.time() < deadline:
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=5)
+                break
+            except OSError:
+                time.sleep(0.02)
+        else:
+            return
+        try:
+            c.sendall(len(payload).to_bytes(8, "little") + payload)      # the round-3 wire format
+            time.sleep(0.5)
+        finally:
+            c.close()
+    results = {}
+
+    def rank(r):
+        os.environ["FASTA_BENCH_TOKEN"] = "feedc0de" * 4
+        if r:
+            time.sleep(1.0)                                               # the stranger gets there first
+        g = bench.SocketGroup(r, 2, f"127.0.0.1:{port}", 30.0)
+        g.barrier()
+        results[r] = (g.broadcast_bytes(b"uid" * 40 if r == 0 else None), g.max(float(r + 1)))
+        g.close()
+    threads = [threading.Thread(target=f, args=a) for f, a in ((rank, (0,)), (stranger, ()), (rank, (1,)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert results == {0: (b"uid" * 40, 2.0), 1: (b"uid" * 40, 2.0)}
+    assert not marker.exists()
+    with pytest.raises(ValueError):                                       # and a malformed frame is an error, not an object
+        a, b = socket.socketpair()
+        a.sendall(b"P" + (5).to_bytes(8, "little") + b"hello")
+        bench.SocketGroup._recv(b)
+
+
+def test_a_rank_stuck_for_good_is_ended_by_the_job_timeout():
+    """A rank that never comes back (as when stuck inside a GPU collective, which no rendezvous timeout covers) must not keep
+    `bench.py --gpus N` alive forever: the spawner's wall-clock limit ends every rank and the status is non-zero."""
+    import time
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--launcher", "socket",
+                          "--hang-at-rank", "1", "--rdv-timeout", "300", "--job-timeout", "6"],
+                         capture_output=True, text=True, timeout=120, env=_bare_env(), cwd=ROOT)
+    assert res.returncode != 0 and "--job-timeout" in res.stderr
+    assert time.time() - t0 < 60
+    assert not [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
