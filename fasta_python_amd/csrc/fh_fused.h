@@ -97,6 +97,10 @@ struct FusedP {
   double* out;
 };
 
+__device__ __forceinline__ double ft_sq(double r) {
+#pragma clang fp contract(off)
+  return r * r;
+}
 __device__ __forceinline__ double ft_sentinel() { return __hiloint2double((int)FT_SENTINEL_HI, (int)FT_SENTINEL_HI); }
 
 // XLDS = 1 (wide rows, PPT 9..16): the member's prox'd x slice lives in LDS (PPT x 4 KiB) instead of PPT x 4 registers per lane.
@@ -128,6 +132,56 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #endif
   FT_PHASE(0);
 
+  // ---------------- rows of this team (bookkeeping first: the row buffers are declared here so that PRELOAD can fill them early)
+  // Row numbers below are TEAM-LOCAL (0 .. r_end-1); grow() maps them to rows of A.  Default: blocked (team t owns a
+  // contiguous range of rows_per_team rows); variant bit 32: row-cyclic over the teams (t, t+nteams, ...), i.e. the whole
+  // grid streams one contiguous window of nteams rows -- measured equal or a little slower (profiles/r01d_fused_tuning.txt).
+  const bool blocked = (p.variant & 32) == 0;
+  const uint32_t row_base = blocked ? min(team * p.rows_per_team, p.mp) : team;
+  const uint32_t row_step = blocked ? 1u : p.nteams;
+  const uint32_t r_begin = 0u;
+  const uint32_t r_end = blocked ? min(row_base + p.rows_per_team, p.mp) - row_base
+                                 : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
+  const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
+  auto grow = [&](uint32_t r) { return row_base + r * row_step; };
+  // Row loads are UNCONDITIONAL (callers clamp the row index to the team's last row; the two surplus reads per team are
+  // noise): hipcc's waitcnt pass merges the pending-load state of both sides of any branch by taking the SMALLER
+  // outstanding count, so a skipped prefetch on one path turns every later `s_waitcnt vmcnt(N)` into "wait for the
+  // newest loads too" -- i.e. no prefetch distance at all.
+  uint32_t pc[PPT];                                  // this lane's piece indices, clamped to the row's last piece
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) pc[k] = min(c0 + k * FH_WG, p.ld2 - 1u);
+  auto load_row = [&](PT (&buf)[PPT], uint32_t r) {
+    const PT* src = reinterpret_cast<const PT*>(p.A) + (uint64_t)grow(r) * p.ldp;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + pc[k]);
+  };
+  // number of rotating row buffers of the schedule this instantiation runs (see the three loops below)
+  constexpr int NB = NBO ? NBO : (TEAM == 1 ? (PPT >= 8 ? 5 : 6) : (!PIPE ? 3 : (PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6))));
+  PT B[NB][PPT];
+  // PRELOAD (round 4, teams of <= 8 members, i.e. n <= 32768 where a launch is short and its fixed cost shows): the first NB - 1 rows
+  // do not depend on the n-side prologue, so their loads are issued BEFORE it -- behind the prologue's own x0 / g0 loads, which
+  // vmcnt retires first -- and land while the forward point and the prox are computed (profiles/r04_sizes.txt).
+  constexpr bool PRELOAD = TEAM <= 8 && !XLDS && PPT <= 8;
+  d2 X0[PRELOAD ? PPT : 1][XD], G0[PRELOAD ? PPT : 1][XD], XA[PRELOAD ? PPT : 1][XD];
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+#pragma unroll
+      for (int h = 0; h < XD; ++h) {
+        const uint32_t ci = pc[k] * XD + h;
+        X0[k][h] = reinterpret_cast<const d2*>(p.x0)[ci];
+        G0[k][h] = reinterpret_cast<const d2*>(p.g0)[ci];
+        XA[k][h] = (d2){0.0, 0.0};
+        if (p.accel) XA[k][h] = reinterpret_cast<const d2*>(p.xacc0)[ci];
+      }
+    }
+    if (r_begin < r_end) {
+#pragma unroll
+      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+    }
+  }
+
   // ---------------- n-side: forward point + prox for this member's slice (registers); team 0 owns the outputs
   d2 xq[XLDS ? 1 : PPT][XD];
   double v[7] = {0, 0, 0, 0, 0, 0, 0};   // dxg0, dx2, xh2, g02, gsum, gmax (team 0 only); [6]: restart dot (every team)
@@ -138,10 +192,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
 #pragma unroll
     for (int h = 0; h < XD; ++h) {
       const uint32_t ci = cl * XD + h, cr = c * XD + h;   // double-pair index: clamped (loads) / real (validity, stores)
-      const d2 x0v = reinterpret_cast<const d2*>(p.x0)[ci];
-      const d2 g0v = reinterpret_cast<const d2*>(p.g0)[ci];
-      d2 xav = {0.0, 0.0};
-      if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[ci];
+      d2 x0v, g0v, xav = {0.0, 0.0};
+      if constexpr (PRELOAD) { x0v = X0[k][h]; g0v = G0[k][h]; xav = XA[k][h]; }
+      else {
+        x0v = reinterpret_cast<const d2*>(p.x0)[ci];
+        g0v = reinterpret_cast<const d2*>(p.g0)[ci];
+        if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[ci];
+      }
       d2 xh, xp;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -171,18 +228,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   }
 
   FT_PHASE(1);
-  // ---------------- rows of this team: one pass, three rotating register buffers ----------------------------
-  // Row numbers below are TEAM-LOCAL (0 .. r_end-1); grow() maps them to rows of A.  Default: blocked (team t owns a
-  // contiguous range of rows_per_team rows); variant bit 32: row-cyclic over the teams (t, t+nteams, ...), i.e. the whole
-  // grid streams one contiguous window of nteams rows -- measured equal or a little slower (profiles/r01d_fused_tuning.txt).
-  const bool blocked = (p.variant & 32) == 0;
-  const uint32_t row_base = blocked ? min(team * p.rows_per_team, p.mp) : team;
-  const uint32_t row_step = blocked ? 1u : p.nteams;
-  const uint32_t r_begin = 0u;
-  const uint32_t r_end = blocked ? min(row_base + p.rows_per_team, p.mp) - row_base
-                                 : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
-  const uint32_t r_last = r_end - 1u;                          // only used when the team has rows
-  auto grow = [&](uint32_t r) { return row_base + r * row_step; };
+  // ---------------- rows of this team: one pass, NB rotating register buffers --------------------------------
   d2 ga[PPT][XD];
 #pragma unroll
   for (int k = 0; k < PPT; ++k)
@@ -190,22 +236,23 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     for (int h = 0; h < XD; ++h) ga[k][h] = (d2){0.0, 0.0};
   double fs = 0.0, fsa = 0.0;
   bool dead = false;                                              // a spin timed out: stop exchanging, finish fast
+  // Least-squares loss (round 4): the row's term of the scalar the host turns into f is the square of the gradient factor the
+  // row loop has just formed (r = z - b), so the ONE lane that forms it (lane 0 of wave 0, member 0) adds it up in row order --
+  // instead of a pass after the loop that drains vmcnt, barriers and reads z back through L2 (2-3 us of every member-0
+  // workgroup, on the critical path into the grid barrier).  The logistic loss keeps that pass (log / exp stay out of the loop).
+  const bool lsq_inline = p.loss == LOSS_LSQ;
+  // (a macro, not a lambda: captured by reference inside the lane-0 branches of the row loops, fs / fsa ended up in scratch memory,
+  // and their scratch loads' vmcnt(0) drained every prefetched row on every trip: +19 % at every size)
+#define FT_LSQ_TERMS(zs_, rv_, bi_, gr_)                                                                   \
+  do {                                                                                                     \
+    if (lsq_inline && (gr_) < p.m) {                                                                       \
+      if (p.accel) { fs = add_nofma(fs, loss_term((zs_), (bi_), LOSS_LSQ)); fsa = add_nofma(fsa, ft_sq((rv_))); }          \
+      else fs = add_nofma(fs, ft_sq((rv_)));                                                               \
+    }                                                                                                      \
+  } while (0)
 #ifdef FT_PROFILE
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-
-  // Row loads are UNCONDITIONAL (callers clamp the row index to the team's last row; the two surplus reads per team are
-  // noise): hipcc's waitcnt pass merges the pending-load state of both sides of any branch by taking the SMALLER
-  // outstanding count, so a skipped prefetch on one path turns every later `s_waitcnt vmcnt(N)` into "wait for the
-  // newest loads too" -- i.e. no prefetch distance at all.
-  uint32_t pc[PPT];                                  // this lane's piece indices, clamped to the row's last piece
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) pc[k] = min(c0 + k * FH_WG, p.ld2 - 1u);
-  auto load_row = [&](PT (&buf)[PPT], uint32_t r) {
-    const PT* src = reinterpret_cast<const PT*>(p.A) + (uint64_t)grow(r) * p.ldp;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) buf[k] = load_stream<NT>(src + pc[k]);
-  };
   // wave 0 (uniform): wait for the eight partials of row r (bounded), return their sum in member order.
   // The slot line is polled with SCALAR loads (`s_load_dwordx16 glc`: past the scalar cache, all eight slots at
   // once): they count on lgkmcnt, so the poll neither waits for this wave's prefetched rows nor for its stores --
@@ -314,11 +361,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // ---- a workgroup owns whole rows (n <= 4096): no exchange at all.  One barrier per trip: the wave partials are
     // double-buffered by trip parity, every thread sums them and evaluates the row's gradient factor itself.
     if (r_begin < r_end) {
-      constexpr int NB = NBO ? NBO : (PPT >= 8 ? 5 : 6);
-      PT B[NB][PPT];
       const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+      if constexpr (!PRELOAD) {
 #pragma unroll
-      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+        for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+      }
       for (uint32_t t = 0; t < trips; t += NB) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -334,7 +381,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           ft_lds_barrier();
           const double zs = ((s_part2[par][0] + s_part2[par][1]) + s_part2[par][2]) + s_part2[par][3];
           const double rv = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
-          if (tid == 0 && live) store_partial(p.z + gr, zs);
+          if (tid == 0 && live) { store_partial(p.z + gr, zs); FT_LSQ_TERMS(zs, rv, bi, gr); }
           update_row(B[j], rv);
         }
       }
@@ -359,8 +406,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
         const double zs = poll_line(gr, live);
         FT_T(4);
         if (lane == 0) {
-          s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
-          if (mem == 0 && live) store_partial(p.z + gr, zs);            // read back below by other lanes of this workgroup
+          const double rv = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
+          s_bc[0] = rv;
+          if (mem == 0 && live) { store_partial(p.z + gr, zs); FT_LSQ_TERMS(zs, rv, bi, gr); }
         }
       }
       FT_T(5);
@@ -373,11 +421,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       // NB rotating buffers: one row is worked on, NB-1 rows of loads stay in flight across the exchange.  Three buffers of 16
       // pieces are all the registers hold next to the x slice; with the slice in LDS (XLDS) there is room for four or five.
       // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
-      constexpr int NB = NBO ? NBO : 3;
-      PT B[NB][PPT];
       const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+      if constexpr (!PRELOAD) {
 #pragma unroll
-      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+        for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+      }
       for (uint32_t t = 0; t < trips; t += NB) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) process_row(B[j], r_begin + t + j, B[(j + NB - 1) % NB], r_begin + t + j + (NB - 1u));
@@ -391,12 +439,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     // NB register buffers rotate: row t is held until its update, row t+1 until the next trip, NB-2 rows prefetch.
     // Trips are padded to a multiple of NB with phantom rows (clamped loads, nothing posted or polled, factor 0).
     constexpr int D = PIPE;                                        // rows between a post and its poll
-    constexpr int NB = NBO ? NBO : (PPT >= 16 ? 3 : (PPT >= 8 ? 5 : 6));     // D+1 rows are held, NB-1-D rows prefetch
-    static_assert(NB >= D + 2, "need at least one prefetching buffer");
-    PT B[NB][PPT];
+    static_assert(NB >= D + 2, "need at least one prefetching buffer");       // D+1 rows are held, NB-1-D rows prefetch
     const uint32_t trips = ((r_end - r_begin + NB - 1u) / NB) * NB;
+    if constexpr (!PRELOAD) {
 #pragma unroll
-    for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+      for (int k = 0; k < NB - 1; ++k) load_row(B[k], min(r_begin + k, r_last));
+    }
     if (wave == 0) {
 #pragma unroll
       for (int q = 0; q < D; ++q) {                                // rows 0..D-1 are posted before the first trip
@@ -423,8 +471,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
           const double zs = poll_line(grow(min(r, r_last)), live);
           FT_T(4);
           if (lane == 0) {
-            s_bc[0] = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
-            if (mem == 0 && live) store_partial(p.z + grow(r), zs);
+            const double rv = live ? loss_grad(p.accel ? extrapolate(zs, za, coef) : zs, bi, p.loss) : 0.0;
+            s_bc[0] = rv;
+            if (mem == 0 && live) { store_partial(p.z + grow(r), zs); FT_LSQ_TERMS(zs, rv, bi, grow(r)); }
           }
           FT_T(5);
           ft_lds_barrier();
@@ -470,7 +519,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   FT_PHASE(2);
   // ---------------- loss terms of this team's rows (member 0), off the exchange's critical path: keeping log/exp of the
   // logistic objective out of the row loop also keeps their constants out of its (full) register budget
-  if (mem == 0) {
+  if (mem == 0 && !lsq_inline) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (uint32_t i = tid; i < r_end; i += FH_WG) {

@@ -895,19 +895,25 @@ __global__ __launch_bounds__(FH_WG) void k_extrapolate_vec(double* out, const do
 // =================================================================================================
 #define TVZ_OWN 60
 
-// neighbour exchange by DPP wavefront shifts (VALU, no LDS crossbar round trip): lane i <- lane i-1 / lane i+1; the end lane
-// keeps its own value (it is a halo lane whose result is never used)
-__device__ __forceinline__ double tvz_from_left(double v) {       // == __shfl_up(v, 1)
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xF, 0xF, false);   // wave_shr:1
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xF, 0xF, false);
+// neighbour exchange by DPP wavefront shifts (VALU, no LDS crossbar round trip): lane i <- lane i-1 / lane i+1.  The end lane has
+// no source and reads 0 (bound_ctrl): it is a halo lane whose result is never used -- and with no "old" value to preserve, the shift
+// is ONE v_mov_b32_dpp per half instead of a copy plus the shift (round 4: 8 fewer vector instructions per pixel row).
+__device__ __forceinline__ double tvz_from_left(double v) {       // == __shfl_up(v, 1) on lanes 1..63
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xF, 0xF, true);   // wave_shr:1
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double tvz_from_right(double v) {      // == __shfl_down(v, 1)
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);   // wave_shl:1
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+__device__ __forceinline__ double tvz_from_right(double v) {      // == __shfl_down(v, 1) on lanes 0..62
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xF, 0xF, true);   // wave_shl:1
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-
+// running maximum of |x| in ONE v_max_f64 (fmax(m, fabs(x)) compiles to three: hipcc canonicalises both operands first)
+__device__ __forceinline__ double tvz_max_abs(double m, double x) {
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(x));
+  return r;
+}
 
 // ---- LDS-DMA helpers for the RING form of k_tv_onepass (round 4) ----------------------------------------------------------------
 // One `global_load_lds_dwordx4`: every lane names its own 16-byte SOURCE, the destination is wave-uniform: M0 base + lane * 16.
@@ -933,7 +939,8 @@ struct TvZP {
   double* red; unsigned* counter; double* out;
 };
 
-// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores (FH_TUNE_TV_NT: 0 none, 1 both, 2 stores only, 3 loads only)
+// NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores.  The host only instantiates NT = 2 (non-temporal stores, the default)
+// and NT = 0 (plain accesses, FH_TUNE_TV_NT = 3): non-temporal LOADS lose 12 % here (halo columns and rows come back through L2).
 // RING > 0 (round 4): the trips are not loaded into registers but prefetched by LDS-DMA into a ring of RING trip slots PER WAVE
 // (x1 rows 1 KiB each | x0 rows likewise with ACCEL | b rows 512 B each, two rows per DMA instruction).  The wave that issues a
 // DMA is the wave that reads the slot, so its own counted vmcnt is the only ordering needed -- no barrier, no flags; the loads in
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
                   u0[0] = fma(dx, dga, u0[0]);
                   u0[1] = fma(dga, dga, u0[1]);
                   u0[2] += fabs(xp_2[e]);
-                  u0[3] = fmax(u0[3], fabs(xp_2[e]));
+                  u0[3] = tvz_max_abs(u0[3], xp_2[e]);
                   if (ACCEL) {
                     const double dgb = bb_dgrad_rcp(gb[e], xh_2[e], x0_2[e], p.tau, rtau);
                     const double x1 = extrapolate(xp_2[e], q1_2[e], p.coef);                          // (:242)
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
                     u1[1] = fma(dgb, dgb, u1[1]);
                     u1[2] = fma(dh, dh, u1[2]);
                     u1[3] += fabs(x1);
-                    u1[4] = fmax(u1[4], fabs(x1));
+                    u1[4] = tvz_max_abs(u1[4], x1);
                   }
                 }
               }

@@ -98,8 +98,8 @@ enum fh_tuning_key {
                                 team partial; this context's co-residency probe answers no)                                    */
   FH_TUNE_TV_ZFREE = 10,     /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
                                 pixel); 0 = the round-1 kernels that stream z (56 / 80 B per pixel)                          */
-  FH_TUNE_TV_PIPE = 11,      /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 = three rotating
-                                trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto        */
+  FH_TUNE_TV_PIPE = 11,      /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 (2 is taken as 3) = three
+                                rotating trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto   */
   FH_TUNE_TV_XCD = 12,       /* z-free one-pass stencil sweep: deal the workgroup ids out XCD by XCD, so that strips that share halo
                                 cache lines share an L2 (0 = auto = 1 = on, 2 = off: plain blockIdx order)                    */
   FH_TUNE_TV_LDS_PAD = 13,   /* z-free one-pass stencil sweep: bytes of unused dynamic LDS per workgroup (0..65536): an occupancy

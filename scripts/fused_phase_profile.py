@@ -4,7 +4,13 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from fasta_python_amd import hip
-hip.load_library(os.path.join(os.path.dirname(hip.__file__), "libfasta_hip_prof.so"))
+import ctypes
+_lib = os.environ.get("FASTA_PROF_LIB") or os.path.join(os.path.dirname(hip.__file__), "libfasta_hip_prof.so")
+_probe = ctypes.CDLL(_lib)
+for _name in list(hip.SIGNATURES):
+    if not hasattr(_probe, _name):
+        del hip.SIGNATURES[_name]            # an older build lacks newer entry points
+hip.load_library(_lib)
 import fasta_python_amd as fa
 from fasta_python_amd import synthetic
 for n, m in ((4096, 4096), (8192, 8192), (16384, 16384), (16384, 8192), (65536, 8192)):
