@@ -292,9 +292,21 @@ def test_c2_c3_full_size_first_iterations_match_oracle_loop():
             assert solver.fused_steps == extra["max_iters"] + got[kind].backtracks   # every launch of the loop was the one-pass kernel
             rhs[kind] = b
         assert got["lasso_forced_backtracking"].backtracks >= 4
+        # [r4] the same LASSO run ROW-SHARDED: the matrix as 8 in-process row blocks of 8192 rows (all on this GPU), against the SAME oracle
+        # run below -- the sharded path's full-size oracle leg (round 3 compared it with the unsharded HIP run only)
+        op8 = fa.ShardedDenseMatrixMap.synthetic(m, n, seed=0, scale=scale, devices=[0] * 8)
+        try:
+            solver = fa.FBSolver(op8, fa.LeastSquares(rhs["lasso"]), fa.Shrink(0.02), np.zeros(n), verbose=False, **base, max_iters=5)
+            np.random.seed(3)
+            got["lasso_8_row_blocks"] = solver.setup().run()
+            assert solver.fused_steps == 5 + got["lasso_8_row_blocks"].backtracks
+            rhs["lasso_8_row_blocks"] = rhs["lasso"]
+        finally:
+            op8.close()
         A = op.host_rows(0, m)                       # 32 GiB host copy, D2H, shared by the oracle runs
     finally:
         op.close()
+    runs = runs + (("lasso_8_row_blocks", 0.01, dict(max_iters=5)),)
     for kind, _, extra in runs:
         iters = extra["max_iters"]
         P = pr.nn_least_squares_from(A, rhs[kind]) if kind == "nnls" else pr.sparse_least_squares_from(A, rhs[kind], 0.02)
