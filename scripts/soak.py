@@ -54,7 +54,58 @@ def tv(accel):
         return A, fa.LeastSquares(M / 0.1), fa.TVDualBall(), np.zeros(M.shape + (2,)), dict(adaptive=not accel, accelerate=accel)
     return make
 
-which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "tv", "tvacc", "blocks8", "config5"]
+def tv_form(tuning):
+    """round 4: the LDS-DMA ring / the persistent chunk walk of the one-pass TV sweep"""
+    inner = tv(False)
+    def make():
+        A, loss, reg, x0, opts = inner()
+        for k, v in tuning.items():
+            A.ctx.set_tuning(k, v)
+        return A, loss, reg, x0, opts
+    return make
+
+def side_by_side(cus, iters):
+    """round 4: TWO solves at once on this GPU, each on its own thread and context, each one-pass grid capped to `cus` CUs (FH_TUNE_FUSED_CUS):
+    the launches overlap in time; neither may ever time out, and both must produce the bits of a solve that ran alone with the same cap"""
+    import threading
+    m, n = 32768, 65536
+    def one(out, key):
+        A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n), tuning={hip.TUNE_FUSED_CUS: cus})
+        try:
+            b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
+            solver = fa.FBSolver(A, fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n), verbose=False, max_iters=iters, tolerance=0.0)
+            np.random.seed(3)
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                solver.setup()
+                barrier.wait()
+                t0 = time.perf_counter()
+                c = solver.run()
+                dt = time.perf_counter() - t0
+            assert solver.use_fused and solver._fused_backoff == 64 and solver.fused_steps == c.iteration_count + c.backtracks, "a launch timed out / fell back"
+            out[key] = (c.solution.copy(), c.residuals.copy(), c.iteration_count / dt)
+        finally:
+            A.close()
+    res = {}
+    barrier = threading.Barrier(1)
+    one(res, "alone")
+    barrier = threading.Barrier(2)
+    np_seed_lock = threading.Lock()
+    ts = [threading.Thread(target=one, args=(res, k)) for k in ("a", "b")]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    same = all(np.array_equal(res[k][0], res["alone"][0]) and np.array_equal(res[k][1], res["alone"][1], equal_nan=True) for k in ("a", "b"))
+    print(f"two solves side by side, {cus} CUs each ({m}x{n}, {iters} iterations): alone {res['alone'][2]:.1f} it/s; together {res['a'][2]:.1f} + {res['b'][2]:.1f} it/s; "
+          f"no timeout; bitwise identical to the solve that ran alone: {same}", flush=True)
+    assert same
+
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "tv", "tvacc", "blocks8", "config5", "tvring", "tvslots", "pair128"]
+if "pair128" in which:
+    side_by_side(128, 600)
+if "tvring" in which:
+    soak("TV 8192^2 adaptive, FH_TUNE_TV_RING = 2", tv_form({hip.TUNE_TV_RING: 2}), 800)
+if "tvslots" in which:
+    soak("TV 8192^2 adaptive, FH_TUNE_TV_SLOTS = 5 x 32-row chunks", tv_form({hip.TUNE_TV_SLOTS: 5, hip.TUNE_TV_ROWS: 32}), 800)
 if "blocks8" in which:
     soak("LASSO 65536^2 as 8 in-process row blocks", dense_blocks(65536, 8), 1500)
 if "config5" in which:
