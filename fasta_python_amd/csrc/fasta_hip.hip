@@ -672,7 +672,8 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // rank calls it at the same point: FBSolver.setup does).
   // (the shards of an in-process multi-device context are combined by their shell above, in one process: nothing to agree on)
   if (c->comm && !c->owner && c->op == OP_DENSE) {
-    if (c->fused_kind_agreed < 0) {
+    // (cached per local verdict: a new matrix, prox kind or tuning changes the local verdict on every rank alike, and they agree again)
+    if (c->fused_kind_agreed < 0 || c->fused_kind_local != kind) {
       double* w = c->dscal + FH_NSCALARS + 8;            // scratch behind the scalar block
       const double mine[2] = {kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0};
       FH_TRY(use_device(c));
@@ -681,6 +682,7 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
       double all[2] = {1.0, 0.0};
       HIP_TRY(hipMemcpyAsync(all, w, sizeof all, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
+      c->fused_kind_local = kind;
       c->fused_kind_agreed = all[0] != 0.0 ? 0 : (all[1] != 0.0 ? 3 : kind);
     }
     kind = c->fused_kind_agreed;
