@@ -261,10 +261,9 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       c->tv_zfree = value ? 1 : 0; return 0;
     case FH_TUNE_FUSED_CUS:
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
-      if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->fused_kind_agreed = -1; c->slots_sig = 0; }
+      if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->slots_sig = 0; }
       return 0;
     case FH_TUNE_FUSED_VARIANT:
-      if (((int)value ^ c->fused_variant) & 128) c->fused_kind_agreed = -1;
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
@@ -671,21 +670,18 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // 0 everywhere, else any 3 makes it 3.  This makes fh_fused_supported a COLLECTIVE call on a context with a communicator (every
   // rank calls it at the same point: FBSolver.setup does).
   // (the shards of an in-process multi-device context are combined by their shell above, in one process: nothing to agree on)
+  // Deliberately NOT cached: every call on such a context is the same small exchange on every rank, whatever each rank's own verdict
+  // or history is -- a cache keyed on local state could make one rank skip an exchange its peers enter.
   if (c->comm && !c->owner && c->op == OP_DENSE) {
-    // (cached per local verdict: a new matrix, prox kind or tuning changes the local verdict on every rank alike, and they agree again)
-    if (c->fused_kind_agreed < 0 || c->fused_kind_local != kind) {
-      double* w = c->dscal + FH_NSCALARS + 8;            // scratch behind the scalar block
-      const double mine[2] = {kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0};
-      FH_TRY(use_device(c));
-      HIP_TRY(hipMemcpyAsync(w, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-      FH_TRY(sum_over_shards(c, [w](fh_ctx*) { return w; }, 2));
-      double all[2] = {1.0, 0.0};
-      HIP_TRY(hipMemcpyAsync(all, w, sizeof all, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      c->fused_kind_local = kind;
-      c->fused_kind_agreed = all[0] != 0.0 ? 0 : (all[1] != 0.0 ? 3 : kind);
-    }
-    kind = c->fused_kind_agreed;
+    double* w = c->dscal + FH_NSCALARS + 8;            // scratch behind the scalar block
+    const double mine[2] = {kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0};
+    FH_TRY(use_device(c));
+    HIP_TRY(hipMemcpyAsync(w, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    FH_TRY(sum_over_shards(c, [w](fh_ctx*) { return w; }, 2));
+    double all[2] = {1.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(all, w, sizeof all, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    kind = all[0] != 0.0 ? 0 : (all[1] != 0.0 ? 3 : kind);
   }
   *yes = kind;
   return 0;
@@ -877,7 +873,6 @@ extern "C" int fh_comm_init(fh_ctx* c, int nranks, int rank, const void* id128) 
   memcpy(&id, id128, sizeof(id));
   NCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
   c->nranks = nranks; c->rank = rank;
-  c->fused_kind_agreed = -1;
   return 0;
 }
 
@@ -899,7 +894,6 @@ extern "C" int fh_comm_destroy(fh_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     NCCL_TRY(g_rccl.CommDestroy(c->comm));
     c->comm = nullptr; c->nranks = 1; c->rank = 0;
-    c->fused_kind_agreed = -1;
   }
   return 0;
 }

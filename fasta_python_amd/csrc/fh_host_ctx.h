@@ -191,8 +191,6 @@ struct fh_ctx {
   int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
   int coresident = -1;       // -1 = not probed yet; 1 / 0 = fused_ncu() workgroups can / cannot run side by side (co_resident())
   int fused_cus = 0;         // FH_TUNE_FUSED_CUS: the one-pass dense kernel uses at most this many CUs (0 = all the device reports)
-  int fused_kind_agreed = -1; // fh_fused_supported's verdict after the ranks of the communicator agreed on it (-1 = not yet)
-  int fused_kind_local = -1;  // this rank's own verdict at the time of that agreement
   // ---- in-process row sharding (fh_create_ex with ndev > 1; SURVEY.md 8(b)/(e): one host thread, one context per device) ----
   // A context created over several devices is a SHELL: it owns one child context per entry of dev_ids (`shards`), each holding
   // a contiguous block of rows of A and the matching slice of b / z, while x, g, xhat are replicated.  Every entry point of the
