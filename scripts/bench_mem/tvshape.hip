@@ -332,5 +332,11 @@ int main(int argc, char** argv) {
     SSTRIP(2, 1, 170, 0); SSTRIP(2, 1, 170, 1); SSTRIP(2, 1, 170, 2); SSTRIP(2, 3, 170, 0); SSTRIP(2, 3, 170, 1);
     SSTRIP(4, 3, 0, 0); SSTRIP(4, 1, 0, 0); SSTRIP(8, 1, 0, 0); SSTRIP(4, 3, 170, 0); SSTRIP(4, 1, 170, 0);
   }
+  if (set == 11) {
+    printf("=== (11) the review's shape taken literally: ONE workgroup per CU (1024-row chunks, 280 workgroups) resp. two (512 rows), deep LDS-DMA rings, against the product's 5 per CU\n");
+    LSTRIP(60, 8, 1, 0, 0, 1024, 8192, 1); LSTRIP(60, 8, 1, 0, 170, 1024, 8192, 1); LSTRIP(60, 12, 1, 0, 0, 1024, 8192, 1); LSTRIP(60, 12, 1, 0, 170, 1024, 8192, 1);
+    LSTRIP(60, 6, 1, 0, 0, 512, 8192, 1); LSTRIP(60, 6, 1, 0, 170, 512, 8192, 1);
+    LSTRIP(60, 2, 1, 0, 0, 228, 8192, 1); LSTRIP(60, 2, 1, 0, 170, 228, 8192, 1);
+  }
   return 0;
 }
