@@ -187,6 +187,8 @@ class SocketGroup:
         self.rank, self.world, self.local_rank = rank, world, int(os.environ.get("LOCAL_RANK", rank))
         self.force, self.dist = False, self
         self.token = os.environ.get("FASTA_BENCH_TOKEN", "").encode()
+        if not self.token:              # the port is open to every local user: without a job token any connection would pass for a rank
+            raise SystemExit("SocketGroup: FASTA_BENCH_TOKEN is empty -- the rendezvous needs the job's token (bench.py's own spawner sets it)")
         host, port = addr.rsplit(":", 1)
         self.peers = []
         if rank == 0:
@@ -199,7 +201,7 @@ class SocketGroup:
             while len(by_rank) < world - 1:
                 srv.settimeout(max(0.05, deadline - time.time()))
                 conn, _ = srv.accept()                  # socket.timeout after `timeout` seconds in all
-                conn.settimeout(min(timeout, 10.0))
+                conn.settimeout(min(timeout, 1.0))     # the hello frame follows the connect at once: a silent stranger costs the (single-threaded) accept loop 1 s, not 10
                 try:
                     hello = self._recv(conn)
                     ok = (isinstance(hello, bytes) and len(hello) == len(self.token) + 4 and hmac.compare_digest(hello[:-4], self.token))
@@ -404,18 +406,29 @@ def cpu_baseline(A_map, b, mu, n, m_total, rows, iters, repeats):
     }
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
-    (profiles/*_pmc_summary.json, produced by scripts/profile_bench.sh + summarize_profile.py)."""
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of EXACTLY the instantiation this run launched, from the newest committed rocprofv3 PMC summary of this same
+    command (profiles/*_pmc_summary.json, produced by scripts/profile_bench.sh + summarize_profile.py).  `kernel_name` is the full
+    instantiation as rocprofv3 prints it (see fused_kernel_name); a summary that does not hold that very kernel is REFUSED -- the
+    field is null and `traffic_source` says why -- instead of lending another instantiation's bytes."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    for path in reversed(files):                       # newest summary that profiled this kernel
-        with open(path) as fh:
-            data = json.load(fh)
-        hits = [rec["traffic_bytes"] for name, rec in data["kernels"].items() if kernel_substr in name]
-        if hits:                                       # several instantiations (e.g. the float32-storage twin): the headline's is the largest
-            return max(hits), os.path.basename(path)
-    return None, None
+    if not files:
+        return None, "no profiles/*_pmc_summary.json"
+    path = files[-1]                                   # the newest summary only: an older round's kernels are not this build's
+    with open(path) as fh:
+        data = json.load(fh)
+    rec = data["kernels"].get(kernel_name)
+    if rec is None:
+        return None, f"{os.path.basename(path)} holds no launch of {kernel_name}: re-run scripts/profile_bench.sh"
+    return rec["traffic_bytes"], os.path.basename(path)
+
+
+def fused_kernel_name(n, storage, tuning, ncu):
+    """The one-pass instantiation fh_step launches for rows of n columns, spelled as rocprofv3 spells it."""
+    from fasta_python_amd import hip
+    (ppt, pipe, team, xlds, nbo), inst = hip.fused_shape(n, storage, tuning.get(hip.TUNE_FUSED_VARIANT, 2) & 0xFFFF, ncu)
+    return f"void k_fused_dense<{ppt}, 1, {pipe}, {team}, {xlds}, {nbo}, {1 if storage == 'f32' else 0}>(FusedP)" if inst else None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -459,7 +472,7 @@ def timed_steps(make_solver, ctx, grp, warmup, steps, repeats=1, trace=False):
             ctx.timing_enable(False)
         elapsed = grp.max(t1 - t0)
         k = {name: ctx.timing_get(kid) for name, kid in
-             (("fwd", hip.K_FWD), ("adj", hip.K_ADJ), ("comm", hip.K_COMM), ("fused", hip.K_FUSED), ("aux", hip.K_AUX))}
+             (("fwd", hip.K_FWD), ("adj", hip.K_ADJ), ("comm", hip.K_COMM), ("fused", hip.K_FUSED), ("aux", hip.K_AUX), ("level", hip.K_LEVEL))}
         runs.append({"elapsed": elapsed, "backtracks": solver.total_backtracks - bt0, "fused_steps": solver.fused_steps - fs0, "k": k,
                      "solver": solver, "step_ms": step_ms})
     order = sorted(range(len(runs)), key=lambda i: runs[i]["elapsed"])
@@ -505,7 +518,9 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     x_true = synthetic.sparse_signal(n, seed=1)
     b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=sigma, row0=row0, m_total=m_total)
     loss = fa.LeastSquares(b)
-    reg = fa.Shrink(mu) if workload == "lasso" else fa.NonNeg()
+    if workload == "l1ball":        # examples/lasso.py:45,66: proxg = project_L1_ball(x, mu), mu = 0.8 ||x_true||_1 (sort-free level search on the device)
+        mu = 0.8 * float(np.abs(x_true).sum())
+    reg = {"lasso": fa.Shrink, "nnls": lambda _: fa.NonNeg(), "l1ball": fa.L1Ball, "linf": fa.LinfProx}[workload](mu)
     def make_solver():
         np.random.seed(3)       # same Lipschitz probes on every rank, in every repeat
         return fa.FBSolver(A, loss, reg, np.zeros(n), adaptive=not (accelerate or plain), accelerate=accelerate, verbose=False,
@@ -515,8 +530,14 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
     # per LAUNCH: a multi-device context launches once per row block (its timers add up launches and time over the blocks)
     by = dense_bytes(m_local // blocks, n, 4 if getattr(A, "storage", "f64") == "f32" else 8)
     per = {"fasta_fwd(k_fwd_dense)": t["k"]["fwd"] + (by["fwd"],), "fasta_adj(k_adj_dense)": t["k"]["adj"] + (by["adj"],),
-           "fasta_step(k_fused_dense)": t["k"]["fused"] + (by["fused"],)}
+           "fasta_step(k_fused_dense)": t["k"]["fused"] + (by["fused"],),
+           # the clipping-level search in front of every forward launch of the l-infinity prox / l1-ball kinds: reads x0 and g0
+           "fasta_level(k_level_search)": t["k"]["level"] + (2 * n * 8,)}
     dom, table = kernel_table(per)
+    if blocks > 1 and getattr(ctx, "devices", None) and len(set(ctx.devices)) == 1:
+        # row blocks that share ONE device are timed on one block (the middle one) and scaled by the number of blocks: an estimate
+        for row in table.values():
+            row["timing"] = f"1 of {blocks} blocks x {blocks} (sampled, fh_timing_enable)"
     loop_bytes = sum(v[1] * v[2] for v in per.values())
     # SURVEY.md 8(d) prices every iteration at TWO passes over A (N_A = iters + backtracks, N_AH = iters)
     model_bytes = ((steps + t["backtracks"]) * by["fwd"] + steps * by["adj"])
@@ -530,6 +551,7 @@ def run_dense(args, grp, A, m_total, n, workload, fused, steps, warmup, accelera
                               "note": "SURVEY.md 8(d) byte model (A read twice per iteration) / wall-clock: exceeds the spec peak "
                                       "when the one-pass kernel reads A once"},
         "comm_avg_ms": comm_ms / comm_cnt if comm_cnt else None, "comm_launches": comm_cnt,
+        "level_search_share_of_kernel_time": (t["k"]["level"][0] / sum(v[0] for v in per.values()) if t["k"]["level"][1] else None),
         "solver": solver, "b": b, "mu": mu, "spread": t["spread"],
     }
 
@@ -567,7 +589,8 @@ def sub_result(r, workload):
     return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
             "backtracks_in_timed_steps": r["backtracks"], "kernel": r["dominant"], "avg_launch_ms": d.get("avg_ms"),
             "achieved_GB/s": d.get("GB/s"), "frac": d.get("GB/s") / HBM_PEAK_GBS if d else None,
-            "per_kernel": r["per_kernel"], "spread": r.get("spread")}
+            "per_kernel": r["per_kernel"], "spread": r.get("spread"),
+            **({"level_search_share_of_kernel_time": r["level_search_share_of_kernel_time"]} if r.get("level_search_share_of_kernel_time") is not None else {})}
 
 
 def tv_bytes(P, accelerate, zfree=True):
@@ -642,8 +665,9 @@ def tv_line(args, r, accelerate):
         "config": {"workload": f"TV denoising {side}x{side} float64 (BASELINE config 4), {'FISTA' if accelerate else 'adaptive FBS'} with backtracking",
                    "backtracks_in_timed_steps": r["backtracks"], "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["GB/s"] / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(("k_tv_onepass<0, 1" if accelerate else "k_tv_onepass<0, 0") if "k_tv_onepass" in r["dominant"] else
-                                            ("k_fwd_tv_step" if "fwd" in r["dominant"] else "k_adj_tv_step"))[0] if side == 8192 else None,
+                     # (the sweep's default instantiations: plain 2-row trips in one buffer, FISTA 4-row trips in three; non-temporal stores)
+                     "traffic": pmc_traffic(("void k_tv_onepass<0, 1, 4, 2, 3, 0>(TvZP)" if accelerate else "void k_tv_onepass<0, 0, 2, 2, 1, 0>(TvZP)"))[0]
+                                if side == 8192 and "k_tv_onepass" in r["dominant"] and not args.tune else None,
                      "kernel": r["dominant"], "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "per_kernel": r["per_kernel"], "loop_GB/s_wallclock": r["loop_GB/s_wallclock"],
                      "vs_materialised_model": r["vs_materialised_model"]},
@@ -721,12 +745,14 @@ def main(argv=None):
     main_r = run_dense(args, grp, A, m_total, n, args.workload, fused, args.steps, args.warmup, args.accelerate, repeats=args.repeats)
     dom = main_r["dominant"]
     d = main_r["per_kernel"][dom]
-    traffic, traffic_src = (pmc_traffic("k_fused_dense" if "fused" in dom else ("k_adj_dense" if "adj" in dom else "k_fwd_dense<8, 1, 1>"))
-                            if (m_total, n, args.gpus) == (65536, 65536, 1) else (None, None))
+    ncu = ctx.cu_count()[0]
+    dom_kernel = (fused_kernel_name(n, args.storage, tuning, ctx.cu_count()[1]) if "fused" in dom else
+                  ("void k_adj_dense<4, 1, 0>(AdjP)" if "adj" in dom else "void k_fwd_dense<8, 1, 1, 0>(FwdP)"))
+    traffic, traffic_src = (pmc_traffic(dom_kernel) if (m_total, n, args.gpus, args.storage) == (65536, 65536, 1, "f64") and dom_kernel
+                            else (None, "PMC summaries are taken at the default configuration (65536 x 65536 float64, 1 GPU) only"))
     # read-only ceiling on the same buffer: the probe with one and with two persistent workgroups per CU (the one-pass kernel itself
     # can only have one: it uses the whole register file), the better of the two is the ceiling quoted
     ceilings = {}
-    ncu = ctx.cu_count()[0]
     for wg_per_cu in (1, 2):
         ctx.set_tuning(hip.TUNE_FWD_GRID_CAP, ncu * wg_per_cu)
         ms, ceil_bytes = ctx.stream_read_ms(3)
@@ -763,7 +789,7 @@ def main(argv=None):
                    "parallelism": (f"row-shard x{args.gpus}" + (" in-process" if args.inproc else "")) if args.gpus > 1 else "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": dom, "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                     "kernel": dom, "kernel_instantiation": dom_kernel, "avg_launch_ms": d["avg_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                      "stream_read_ceiling_GB/s": max(ceilings.values()),
                      "stream_read_GB/s_by_workgroups_per_cu": ceilings,
                      "stream_read_probe": "k_stream_probe<16,1> over the same device copy of A: one or two persistent workgroups per CU (best of both), three rotating "
@@ -790,6 +816,12 @@ def main(argv=None):
         extra["lasso_accelerated"] = sub_result(r, f"LASSO {m_total}x{n}, FISTA (accelerate=True, adaptive=False), one launch per iteration (fh_step_accel)")
         r = run_dense(args, grp, A, m_total, n, "lasso", fused, args.steps, args.warmup, plain=True)
         extra["lasso_plain"] = sub_result(r, f"LASSO {m_total}x{n}, plain FBS (adaptive=False, accelerate=False)")
+        # the two sort-free prox kinds (north_star's "l-infinity ball"; fasta/proximal.py:12-41, examples/lasso.py:45): every forward launch is
+        # preceded by the clipping-level search, timed as its own per_kernel row
+        r = run_dense(args, grp, A, m_total, n, "l1ball", fused, args.steps, args.warmup)
+        extra["lasso_l1ball"] = sub_result(r, f"l1-ball constrained LASSO {m_total}x{n} (examples/lasso.py: proxg = project_L1_ball(x, 0.8 ||x_true||_1)), same matrix")
+        r = run_dense(args, grp, A, m_total, n, "linf", fused, args.steps, args.warmup)
+        extra["linf"] = sub_result(r, f"least squares + {0.02} ||x||_inf on the same {m_total}x{n} matrix (proxg = project_Linf_ball(x, t mu), fasta/proximal.py:12-31)")
         if args.gpus > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
             # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
             A.close()

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/fasta_hip.h"
+#include "fh_experimental.h"
 #include "fh_dense.h"
 #include "fh_tv.h"
 #include "fh_prox.h"
@@ -241,6 +242,7 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_PIPE:
       if (value < 0 || value > 3) return fail(FH_E_ARG, "TV_PIPE must be 0 (auto), 1 (load a trip, consume it) or 3 (three rotating trip buffers; 2 is taken as 3)");
       c->tv_pipe = (int)value; return 0;
+#ifdef FH_EXPERIMENTAL
     case FH_TUNE_TV_SLOTS:
       if (value < 0 || value > 8) return fail(FH_E_ARG, "TV_SLOTS must be in [0, 8] workgroups per CU (0 = one workgroup per chunk)");
       c->tv_slots = (int)value; return 0;
@@ -250,22 +252,32 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
     case FH_TUNE_TV_LDS_PAD:
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "TV_LDS_PAD must be in [0, 65536] bytes");
       c->tv_lds_pad = (int)value; return 0;
-    case FH_TUNE_TV_XCD:
-      if (value < 0 || value > 2) return fail(FH_E_ARG, "TV_XCD must be 0 (auto), 1 (on) or 2 (off)");
-      c->tv_xcd = (int)value; return 0;
     case FH_TUNE_TV_ZFREE:
       // while the iterate is kept lazily (one-pass FISTA on the stencil), z-free steps rotate their image buffers without ever
       // writing them: the z-streaming kernel would read stale images after a switch
       if (c->lazy && (value ? 1 : 0) != c->tv_zfree)
         return fail(FH_E_STATE, "TV_ZFREE cannot change while a one-pass accelerated stencil solve is in flight (call fh_init / fh_set_vector(X0) first)");
       c->tv_zfree = value ? 1 : 0; return 0;
+#else
+    case FH_TUNE_TV_SLOTS: case FH_TUNE_TV_RING: case FH_TUNE_TV_LDS_PAD: case FH_TUNE_TV_ZFREE:
+      return fail(FH_E_ARG, "tuning key %d is an experimental form of the stencil sweep: only in libfasta_hip_experimental.so (make experimental, csrc/fh_experimental.h)", key);
+#endif
+    case FH_TUNE_TV_XCD:
+      if (value < 0 || value > 2) return fail(FH_E_ARG, "TV_XCD must be 0 (auto), 1 (on) or 2 (off)");
+      c->tv_xcd = (int)value; return 0;
     case FH_TUNE_FUSED_CUS:
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
       if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->slots_sig = 0; }
       return 0;
     case FH_TUNE_FUSED_VARIANT:
+      // (bits 64 / 128 were test hooks until round 4: a caller's variant word must not be able to switch the one-pass kernel off)
+      if (value & 0xFFC1) return fail(FH_E_ARG, "FUSED_VARIANT: only the scheduling bits 2, 4, 8, 16, 32 are defined (got 0x%llx)", (unsigned long long)(value & 0xFFFF));
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
+      return 0;
+    case FH_TUNE_TEST_HOOKS:        // not in the public header (csrc/fh_experimental.h): fault injection for the test-suite
+      if (value & ~3ll) return fail(FH_E_ARG, "TEST_HOOKS: bits 1 and 2 only");
+      if ((int)value != c->test_hooks) { c->test_hooks = (int)value; c->coresident = -1; }
       return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
   }
@@ -641,6 +653,8 @@ extern "C" int fh_fwd_adj(fh_ctx* c, double tau, double* scalars) {
   return fetch_scalars(c, scalars);
 }
 
+// A purely LOCAL query (no exchange, safe to call from one rank alone, e.g. for logging): what THIS context's shape and THIS
+// context's co-residency probe say.  Ranks of a row-sharded run settle on one verdict with fh_fused_agree below.
 extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
   if (!c->shards.empty()) {          // shell: what every shard supports (row blocks may differ by one row; the kinds rarely differ)
@@ -664,26 +678,38 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
   // safety net for CUs that disappear later).
   if (ppt && !co_resident(c)) ppt = 0;
   int kind = c->op == OP_STENCIL ? (row_sharded(c) ? 0 : 2) : (ppt ? (fused_pays(c) ? 1 : 3) : 0);
-  // One process per GPU: the verdict must be the SAME on every rank -- a rank whose probe said no would otherwise take fh_fwd /
-  // fh_adj (exchanges of 1, then n + 1 doubles) while its peers take fh_step (one exchange of n + 3): mismatched collectives, i.e. a
-  // hang.  So the ranks agree once per context state: counts of "0" and "3" verdicts are summed over the communicator; any 0 makes it
-  // 0 everywhere, else any 3 makes it 3.  This makes fh_fused_supported a COLLECTIVE call on a context with a communicator (every
-  // rank calls it at the same point: FBSolver.setup does).
-  // (the shards of an in-process multi-device context are combined by their shell above, in one process: nothing to agree on)
-  // Deliberately NOT cached: every call on such a context is the same small exchange on every rank, whatever each rank's own verdict
-  // or history is -- a cache keyed on local state could make one rank skip an exchange its peers enter.
-  if (c->comm && !c->owner && c->op == OP_DENSE) {
-    double* w = c->dscal + FH_NSCALARS + 8;            // scratch behind the scalar block
-    const double mine[2] = {kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0};
-    FH_TRY(use_device(c));
-    HIP_TRY(hipMemcpyAsync(w, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    FH_TRY(sum_over_shards(c, [w](fh_ctx*) { return w; }, 2));
-    double all[2] = {1.0, 0.0};
-    HIP_TRY(hipMemcpyAsync(all, w, sizeof all, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    kind = all[0] != 0.0 ? 0 : (all[1] != 0.0 ? 3 : kind);
-  }
   *yes = kind;
+  return 0;
+}
+
+// One process per GPU: the verdict must be the SAME on every rank -- a rank whose probe said no would otherwise take fh_fwd / fh_adj
+// (exchanges of 1, then n + 1 doubles) while its peers take fh_step (one exchange of n + 3): mismatched collectives, i.e. a hang.
+// fh_fused_agree is the explicitly COLLECTIVE form: every rank of the communicator calls it at the same point (FBSolver.setup
+// does); the counts of "0" and "3" verdicts are summed over the ranks, any 0 makes it 0 everywhere, else any 3 makes it 3.  A rank
+// whose local query FAILED still enters the exchange, contributing a "0" verdict, so that its peers get an answer instead of a
+// hang; the failure is then returned on that rank.  Never cached: a cache keyed on local state could make one rank skip an
+// exchange its peers enter.  Without a communicator (plain context, or a multi-device context, whose shards are combined in one
+// process) it is the local query.
+static __global__ void k_set_pair(double* w, double a, double b) { w[0] = a; w[1] = b; }
+extern "C" int fh_fused_agree(fh_ctx* c, int* yes) {
+  if (!c || !yes) return fail(FH_E_ARG, "null argument");
+  int kind = 0;
+  const int rc_local = fh_fused_supported(c, &kind);
+  if (rc_local != 0) kind = 0;
+  if (!c->comm || c->owner || !c->shards.empty() || c->op != OP_DENSE) { *yes = kind; return rc_local; }
+  char keep[sizeof(g_err)];
+  memcpy(keep, g_err, sizeof(keep));                   // (the text of a local failure survives the exchange)
+  double* w = c->dscal + FH_NSCALARS + 8;              // scratch behind the scalar block
+  double* back = c->hscal + FH_NSCALARS + 8;           // pinned: no stack buffer is ever handed to an asynchronous copy
+  (void)hipSetDevice(c->device);
+  k_set_pair<<<dim3(1), dim3(1), 0, c->stream>>>(w, kind == 0 ? 1.0 : 0.0, kind == 3 ? 1.0 : 0.0);   // (values travel as kernel arguments)
+  (void)hipGetLastError();
+  const int rc_sum = sum_over_shards(c, [w](fh_ctx*) { return w; }, 2);
+  if (rc_local != 0) { memcpy(g_err, keep, sizeof(keep)); return rc_local; }
+  FH_TRY(rc_sum);
+  HIP_TRY(hipMemcpyAsync(back, w, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *yes = back[0] != 0.0 ? 0 : (back[1] != 0.0 ? 3 : kind);
   return 0;
 }
 
@@ -702,7 +728,8 @@ extern "C" const char* fh_comm_library(void) { return g_rccl_path; }
 // shard -> ONE sum over the row blocks of g1 with the local loss sums and the timeout word appended (every shard / rank then sees
 // the same verdict, so all of them drop to the two-launch path together if a hand-off ever times out) -> the n-side epilogue on
 // every shard -> one host synchronisation.  A plain single-GPU context is the one-shard case without the exchange.
-static int dense_step(fh_ctx* c, double tau, int accel, double coef, int restart, double* scalars) {
+static void step_collected(fh_ctx* c) { for (int k = 0; k < nshards(c); ++k) fused_after(shard_of(c, k)); }
+static int dense_step(fh_ctx* c, double tau, int accel, double coef, int restart, double* scalars, bool wait = true) {
   const int ns = nshards(c);
   if (c->timing) { c->issue_t0 = std::chrono::steady_clock::now(); c->issue_open = true; }
   for (int k = 0; k < ns; ++k) {
@@ -731,30 +758,52 @@ static int dense_step(fh_ctx* c, double tau, int accel, double coef, int restart
     double* pack = io.g1 + s->nv;
     FH_TRY(bb_epilogue_only(s, io, accel ? pack + 2 : pack, accel ? s->dscal + FH_NSCALARS + 3 : nullptr, pack));
   }
-  FH_TRY(fetch_scalars(c, scalars));
-  for (int k = 0; k < ns; ++k) fused_after(shard_of(c, k));
+  FH_TRY(issue_scalars(c));
+  if (!wait) { c->pending_step = true; return 0; }
+  FH_TRY(collect_scalars(c, scalars));
+  step_collected(c);
   return 0;
 }
 
 // One-pass FBS iteration: K-fwd and K-adj of the same tau from a single read of A (no acceleration).
 // Writes the complete FH_S_* block; scalars[15] != 0 reports a spin timeout (results invalid: use the two-launch path).
-extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) {
+static int step_body(fh_ctx* c, double tau, double* scalars, bool wait) {
   FH_TRY(check_ready(c, true));
   for (int k = 0; k < nshards(c); ++k) FH_TRY(not_lazy(shard_of(c, k), "fh_step"));
   if (c->op == OP_STENCIL) {
     if (row_sharded(c)) return fail(FH_E_STATE, "row sharding is implemented for the dense operator only");
-    if (c->tv_zfree) {
-      if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
-      FH_TRY(launch_tv_onepass(c, tau, 0, 0.0, 0));
-    } else {
+#ifdef FH_EXPERIMENTAL
+    if (!c->tv_zfree) {
       FH_TRY(tv_refresh_zcur(c));
       c->tvz_pending = false;
       FH_TRY(launch_fused_tv(c, tau));
+    } else
+#endif
+    {
+      if (!c->zcur) return fail(FH_E_STATE, "fh_step on the stencil operator before fh_init");
+      FH_TRY(launch_tv_onepass(c, tau, 0, 0.0, 0));
     }
     c->last_accel = false;
-    return fetch_scalars(c, scalars);
+    FH_TRY(issue_scalars(c));
+    if (!wait) { c->pending_step = true; return 0; }
+    return collect_scalars(c, scalars);
   }
-  return dense_step(c, tau, 0, 0.0, 0, scalars);
+  return dense_step(c, tau, 0, 0.0, 0, scalars, wait);
+}
+extern "C" int fh_step(fh_ctx* c, double tau, double* scalars) { return step_body(c, tau, scalars, true); }
+// fh_step in two halves: fh_step_begin issues the launch(es) on the context's stream and returns WITHOUT waiting; fh_step_end is the
+// wait and delivers the scalar block.  Between the two the host is free -- in particular to issue a step on ANOTHER context, which
+// is how one host thread keeps two solves (FH_TUNE_FUSED_CUS each) in flight on one device.  Every other entry point of the
+// context refuses (FH_E_STATE) until fh_step_end has been called.
+extern "C" int fh_step_begin(fh_ctx* c, double tau) { return step_body(c, tau, nullptr, false); }
+extern "C" int fh_step_end(fh_ctx* c, double* scalars) {
+  if (!c) return fail(FH_E_ARG, "null context");
+  if (!c->pending_step) return fail(FH_E_STATE, "fh_step_end without fh_step_begin");
+  c->pending_step = false;
+  if (c->shards.empty()) FH_TRY(use_device(c));
+  FH_TRY(collect_scalars(c, scalars));
+  if (c->op == OP_DENSE) step_collected(c);
+  return 0;
 }
 
 // One-pass iteration WITH acceleration (fasta/__init__.py:220-248): the launch computes this step's restart dot before
@@ -775,8 +824,11 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
       c->lc = c->lbc = c->lc_pending = 0.0;
       lazy_pick_targets(c);
     }
-    if (c->tv_zfree) FH_TRY(launch_tv_onepass(c, tau, 1, coef, restart ? 1 : 0));
-    else FH_TRY(launch_fused_tv_accel(c, tau, coef, restart ? 1 : 0));
+#ifdef FH_EXPERIMENTAL
+    if (!c->tv_zfree) FH_TRY(launch_fused_tv_accel(c, tau, coef, restart ? 1 : 0));
+    else
+#endif
+    FH_TRY(launch_tv_onepass(c, tau, 1, coef, restart ? 1 : 0));
     c->last_accel = true;
     FH_TRY(fetch_scalars(c, scalars));
     c->lc_pending = (restart && c->hscal[FH_S_RDOT] > 1E-30) ? 0.0 : coef;      // what the launch applied (:231); adopted by fh_commit
@@ -943,6 +995,31 @@ extern "C" int fh_timing_reset(fh_ctx* c) {
   for (fh_ctx* s : c->shards) FH_TRY(fh_timing_reset(s));
   for (int k = 0; k < FH_NKERNELS; ++k) { c->tot_ms[k] = 0; c->launches[k] = 0; c->ev_pending[k] = false; }
   c->host_issue_ms = 0.0; c->host_issue_calls = 0; c->issue_open = false;
+  return 0;
+}
+
+// Did the latest timed launch of kernel k on context a and the latest one on context b (two plain contexts on one device, timing
+// enabled, both launches waited for) run at the same time?  a_ms / b_ms: their durations; overlap_ms: the length of the interval
+// both were running (<= 0: one had ended before the other began), from the HIP events that bracket each launch on its own stream.
+extern "C" int fh_timing_overlap(fh_ctx* a, fh_ctx* b, int k, double* a_ms, double* b_ms, double* overlap_ms) {
+  if (!a || !b || k < 0 || k >= FH_NKERNELS || k == FH_K_HOST_ISSUE) return fail(FH_E_ARG, "fh_timing_overlap: bad argument");
+  if (!a->shards.empty() || !b->shards.empty() || a->device != b->device) return fail(FH_E_ARG, "fh_timing_overlap takes two plain contexts on one device");
+  if (!a->launches[k] || !b->launches[k] || a->ev_pending[k] || b->ev_pending[k] || a->pending_step || b->pending_step)
+    return fail(FH_E_STATE, "fh_timing_overlap: both contexts need a completed, timed launch of kernel %d", k);
+  FH_TRY(use_device(a));
+  // signed time from event e1 to event e2 (whichever way round the runtime is willing to subtract them)
+  auto between = [](hipEvent_t e1, hipEvent_t e2, float* ms) -> hipError_t {
+    hipError_t r = hipEventElapsedTime(ms, e1, e2);
+    if (r != hipSuccess) { (void)hipGetLastError(); r = hipEventElapsedTime(ms, e2, e1); *ms = -*ms; }
+    return r;
+  };
+  float da = 0.f, db0 = 0.f, db1 = 0.f;               // everything relative to the start of a's launch
+  HIP_TRY(between(a->ev[k][0], a->ev[k][1], &da));
+  HIP_TRY(between(a->ev[k][0], b->ev[k][0], &db0));
+  HIP_TRY(between(a->ev[k][0], b->ev[k][1], &db1));
+  if (a_ms) *a_ms = da;
+  if (b_ms) *b_ms = db1 - db0;
+  if (overlap_ms) *overlap_ms = std::min(da, db1) - std::max(0.f, db0);
   return 0;
 }
 

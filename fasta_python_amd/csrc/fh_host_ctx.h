@@ -168,6 +168,7 @@ struct fh_ctx {
   int tv_ring = 0;           // FH_TUNE_TV_RING: LDS-DMA trip ring of the one-pass sweep (0 = auto, 1 = off, 2 / 3 = slots per wave)
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
+  int test_hooks = 0;        // FH_TUNE_TEST_HOOKS (csrc/fh_experimental.h): fault injection, set by the test-suite only
   int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
   // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
   // the host fills both with the sentinel only when this signature (workspace, layout) changes or a launch timed out
@@ -178,13 +179,13 @@ struct fh_ctx {
   // timing
   bool timing = false;
   hipEvent_t ev[FH_NKERNELS][2];
-  bool ev_pending[FH_NKERNELS] = {false, false, false, false, false, false};
+  bool ev_pending[FH_NKERNELS] = {};
   // FH_K_HOST_ISSUE: host time of a one-pass dense step from its entry to the start of its final synchronisation
   bool timing_skip_kernels = false;
   double host_issue_ms = 0.0; uint64_t host_issue_calls = 0;
   std::chrono::steady_clock::time_point issue_t0; bool issue_open = false;
-  double tot_ms[FH_NKERNELS] = {0, 0, 0, 0, 0, 0};
-  uint64_t launches[FH_NKERNELS] = {0, 0, 0, 0, 0, 0};
+  double tot_ms[FH_NKERNELS] = {};
+  uint64_t launches[FH_NKERNELS] = {};
   // comm
   fh_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0;
@@ -201,6 +202,7 @@ struct fh_ctx {
   std::vector<fh_ctx*> shards;       // non-empty: this context is a shell
   std::vector<uint64_t> shard_row0;  // first row of every shard, plus the total (size shards + 1)
   fh_ctx* owner = nullptr;           // set in a shard
+  bool pending_step = false;         // fh_step_begin has issued a step whose fh_step_end is still to come (every other entry point refuses)
   bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)
   bool owns_stream = true;           // false in shards 1.. of an emulated group (they run on shard 0's stream)
 };
@@ -312,7 +314,10 @@ __global__ void k_forward_scalars(const double* src, double* dst) {
   if (threadIdx.x < FH_NSCALARS) dst[threadIdx.x] = src[threadIdx.x];
 }
 
-static int fetch_scalars(fh_ctx* c, double* scalars) {
+// The scalar block's way back, in two halves so that a step can be issued now and waited for later (fh_step_begin / fh_step_end):
+// issue_scalars enqueues what is still missing (row-sharded contexts forward the block from device memory to the mapped host block)
+// and closes the host-issue stopwatch; collect_scalars is the call's ONE host synchronisation (per device of a shell) and the copy out.
+static int issue_scalars(fh_ctx* c) {
   for (int k = 0; k < nshards(c); ++k) {
     fh_ctx* s = shard_of(c, k);
     const bool mirrored = s->scal_mirrored;
@@ -328,10 +333,17 @@ static int fetch_scalars(fh_ctx* c, double* scalars) {
     c->host_issue_calls += 1;
     c->issue_open = false;
   }
+  return 0;
+}
+static int collect_scalars(fh_ctx* c, double* scalars) {
   FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
   // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors
   if (scalars) memcpy(scalars, shard_of(c, 0)->hscal, FH_NSCALARS * sizeof(double));
   return 0;
+}
+static int fetch_scalars(fh_ctx* c, double* scalars) {
+  FH_TRY(issue_scalars(c));
+  return collect_scalars(c, scalars);
 }
 
 // ---- sums over the row blocks ------------------------------------------------------------------------------------------

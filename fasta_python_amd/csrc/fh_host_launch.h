@@ -166,13 +166,13 @@ static int launch_level_search(fh_ctx* c, double tau) {
   const double* g0 = c->G[c->gc];
   double* out = c->dscal + FH_NSCALARS;
   const uint32_t n = (uint32_t)c->n;
-  t_begin(c, FH_K_AUX);
+  t_begin(c, FH_K_LEVEL);
   if (n <= 1u * LVL_WG) k_level_search<1><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 4u * LVL_WG) k_level_search<4><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 16u * LVL_WG) k_level_search<16><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 64u * LVL_WG) k_level_search<64><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else k_level_search<0><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  t_end(c, FH_K_AUX);
+  t_end(c, FH_K_LEVEL);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -415,7 +415,8 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     c->slots_sig = 0;
   }
   p.g1 = io.g1;
-  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR; p.variant = c->fused_variant;
+  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
   {
@@ -477,7 +478,7 @@ static bool run_coresident_probe(fh_ctx* c, unsigned grid) {                    
   return host[1] == 0 && host[0] == grid;
 }
 static bool co_resident(fh_ctx* c) {
-  if (c->fused_variant & 128) return false;          // test hook (FH_TUNE_FUSED_VARIANT bit 128): "this rank's probe said no"
+  if (c->test_hooks & FH_HOOK_PROBE_SAYS_NO) return false;      // test hook (FH_TUNE_TEST_HOOKS, csrc/fh_experimental.h): "this rank's probe said no"
   if (c->coresident >= 0) return c->coresident != 0;
   // (the probe decides, nothing else: no environment variable is consulted.  A second try: a transient co-tenant must not cost this
   // context the one-pass kernel.)
@@ -547,6 +548,7 @@ static int reduce_fsq_over_ranks(fh_ctx* c) {
 
 static int check_ready(fh_ctx* c, bool need_b) {
   if (!c) return fail(FH_E_ARG, "null context");
+  if (c->pending_step) return fail(FH_E_STATE, "a step issued by fh_step_begin is still in flight on this context: call fh_step_end first");
   if (c->op == OP_NONE) return fail(FH_E_STATE, "no operator set (call fh_set_matrix / fh_generate_matrix / fh_set_stencil)");
   if (need_b && !c->has_b) return fail(FH_E_STATE, "no loss set (call fh_set_loss_lsq)");
   return c->shards.empty() ? use_device(c) : 0;      // (a shell selects the device shard by shard)
@@ -572,6 +574,7 @@ static int solver_fwd_local(fh_ctx* c, double tau, const char* who) {
 }
 
 // ---- stencil one-pass launchers ---------------------------------------------------------------------------------------------
+#ifdef FH_EXPERIMENTAL      // the round-1 one-pass stencil kernels that stream z (FH_TUNE_TV_ZFREE = 0, csrc/fh_experimental.h)
 static int launch_fused_tv(fh_ctx* c, double tau) {
   if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
     return fail(FH_E_STATE, "the stencil operator supports the TV-ball prox or no prox (got kind %d)", c->prox_kind);
@@ -626,6 +629,8 @@ static int launch_fused_tv_accel(fh_ctx* c, double tau, double coef, int restart
   return 0;
 }
 
+#endif
+
 // z-free one-pass stencil step (k_tv_onepass): accel = 0 -> x0 = X[xi]; accel = 1 -> the lazily-kept (P1, P0, c) state
 static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int restart) {
   if (c->prox_kind != FH_PROX_TVBALL && c->prox_kind != FH_PROX_IDENTITY)
@@ -654,7 +659,9 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   // FH_TUNE_TV_SLOTS: persistent form -- at most that many workgroups per CU, each walking the chunk ids with the grid as its stride
   // (0 = one workgroup per chunk, the round-3 form)
   unsigned grid = p.nchunks;
+#ifdef FH_EXPERIMENTAL
   if (c->tv_slots > 0) grid = std::min(grid, (unsigned)std::max(1, c->ncu) * (unsigned)c->tv_slots);
+#endif
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
@@ -668,6 +675,7 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
 #define TVZ_NB(AC, U, NT) do { if (nb >= 2) TVZ(0, AC, U, NT, 3); else TVZ(0, AC, U, NT, 1); } while (0)
 #define TVZ_U(AC, NT) do { if (tvu <= 2) TVZ_NB(AC, 2, NT); else if (tvu == 8) TVZ_NB(AC, 8, NT); else TVZ_NB(AC, 4, NT); } while (0)
 #define TVZ_NT(AC) do { if (nts) TVZ_U(AC, 2); else TVZ_U(AC, 0); } while (0)
+#ifdef FH_EXPERIMENTAL
   // FH_TUNE_TV_RING: LDS-DMA trip ring (2-row trips; the b pieces need 16-byte aligned rows, i.e. an even width)
   const int ring = (c->tv_ring >= 2 && p.W % 2 == 0 && !ident) ? c->tv_ring : 0;
 #define TVZ_RING(AC, R) do { if (nts) k_tv_onepass<0, AC, 2, 2, 1, R><<<dim3(grid), dim3(FH_WG), (size_t)c->tv_lds_pad, c->stream>>>(p); \
@@ -676,12 +684,13 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
     if (accel) { if (ring == 2) TVZ_RING(1, 2); else TVZ_RING(1, 3); }
     else { if (ring == 2) TVZ_RING(0, 2); else TVZ_RING(0, 3); }
   } else
+#undef TVZ_RING
+#endif
   if (ident) {        // no prox (g = None): the round-2 burst form
     if (accel) { if (tvu == 2) TVZ(1, 1, 2, 0, 1); else if (tvu == 8) TVZ(1, 1, 8, 0, 1); else TVZ(1, 1, 4, 0, 1); }
     else { if (tvu == 2) TVZ(1, 0, 2, 0, 1); else if (tvu == 8) TVZ(1, 0, 8, 0, 1); else TVZ(1, 0, 4, 0, 1); }
   } else if (accel) TVZ_NT(1);
   else TVZ_NT(0);
-#undef TVZ_RING
 #undef TVZ_NB
 #undef TVZ_NT
 #undef TVZ_U

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_tv_step(const TvStepAdjP p) {
 //   / r_new halos; each workgroup also rolls through one halo row above its chunk (r_new of row i0-1 feeds
 //   g1 of row i0) and looks one row ahead (xprox of row i0+rows feeds z_new of the last row).
 // =================================================================================================
+#ifdef FH_EXPERIMENTAL   // round-1 one-pass stencil kernels that stream z: superseded by k_tv_onepass, kept for A/B runs (csrc/fh_experimental.h)
 #define TVF_OWN 61
 
 template <int IDENT, int TV_U, int NT>
@@ -867,8 +868,10 @@ __global__ __launch_bounds__(FH_WG) void k_fused_tv_accel(const TvAccelP p) {
     }
   }
 }
+#endif   // FH_EXPERIMENTAL
 
 // out = a + coef*(a - b) elementwise (:242): materialises a lazily-kept iterate for fh_get_vector
+
 __global__ __launch_bounds__(FH_WG) void k_extrapolate_vec(double* out, const double* a, const double* b, double coef, uint64_t len) {
   for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < len; i += (uint64_t)gridDim.x * FH_WG)
     out[i] = coef != 0.0 ? extrapolate(a[i], b[i], coef) : a[i];
@@ -1091,6 +1094,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
     }
     asm volatile("" ::: "memory");
   };
+#ifdef FH_EXPERIMENTAL
   if constexpr (RING > 0) {
     static_assert(TV_U % 2 == 0, "the RING form pairs the rows of a trip for its b pieces");
     constexpr uint32_t XB = (uint32_t)TV_U * 1024u;                       // the x1 rows of one trip
@@ -1133,15 +1137,19 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       // Younger than trip it's DMAs: the DMAs of the RING - 1 later trips and the stores of the RING - 1 trips consumed since (vmcnt
       // counts loads, stores and LDS-DMA together, in issue order).  Only when every one of those trips stored all of its TV_U rows
       // is the larger count exact; waiting for FEWER outstanding operations is always safe.
-      const bool full = stores && (it - (RING - 1)) * TV_U >= 3 && (it - 1) * TV_U + TV_U - 3 <= (int)rows;
-      if (lag) { if (full) tv_wait_vm<(RING - 1) * (G2 + TV_U)>(); else tv_wait_vm<(RING - 1) * G2>(); }
-      else { if (full) tv_wait_vm<(RING - 1) * (G1 + TV_U)>(); else tv_wait_vm<(RING - 1) * G1>(); }
+      // (round 4 took the larger count whenever TV_U stores per consumed trip could be assumed; nothing in the build pins the number of
+      // store instructions hipcc emits per trip, and assuming too many would read a slot before its DMA has landed.  vmcnt retires
+      // loads, stores and LDS-DMA in issue order, so waiting for the DMAs alone is always safe.)
+      (void)stores;
+      if (lag) tv_wait_vm<(RING - 1) * G2>(); else tv_wait_vm<(RING - 1) * G1>();
       Trip T0;
       read_trip(T0, it);
       eat_trip(T0, it * TV_U);
     }
     tv_wait_vm<0>();                                                      // the clamped DMAs past the chunk still target this wave's ring
-  } else if constexpr (NB == 3) {
+  } else
+#endif
+  if constexpr (NB == 3) {
     // three rotating trips: two stay in flight behind the one being consumed -- the shape that sustains this read/write mix
     // best in scripts/bench_mem/mixprobe.hip (in the burst form below the waves sit in s_waitcnt 65 % of their cycles)
     Trip T0, T1, T2;

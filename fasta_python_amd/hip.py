@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfasta_hip.so")
+# $FASTA_HIP_LIB names another build of the SAME C ABI (the test job of the experimental stencil forms points it at
+# libfasta_hip_experimental.so, csrc/fh_experimental.h); it is never a fallback: a path that does not exist is an error
+LIB_PATH = os.environ.get("FASTA_HIP_LIB") or os.path.join(_HERE, "libfasta_hip.so")
 
 # enums mirrored from include/fasta_hip.h ---------------------------------------------------------
 PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PROX_BOX = range(7)
@@ -19,10 +21,15 @@ PROX_IDENTITY, PROX_SHRINK, PROX_NONNEG, PROX_LINF, PROX_L1BALL, PROX_TVBALL, PR
 (S_FSQ, S_DXG0, S_DX2, S_XH2, S_G02, S_GSUM, S_GMAX, S_RDOT, S_DXDG, S_DG2, S_FSQ_ADJ, S_XH2_ADJ,
  S_GSUM_ADJ, S_GMAX_ADJ, S_ALPHA) = range(15)
 NSCALARS = 16
-K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED, K_HOST_ISSUE = range(6)
+K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED, K_HOST_ISSUE, K_LEVEL = range(7)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
  TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS) = range(17)
+# keys 10, 13, 14, 15 (TUNE_TV_ZFREE / _LDS_PAD / _RING / _SLOTS) are NOT in include/fasta_hip.h: experimental forms of the stencil sweep,
+# accepted only by libfasta_hip_experimental.so (csrc/fh_experimental.h); the shipped library answers FH_E_ARG
+EXPERIMENTAL_KEYS = (TUNE_TV_ZFREE, TUNE_TV_LDS_PAD, TUNE_TV_RING, TUNE_TV_SLOTS)
+TUNE_TEST_HOOKS = 0x7E57             # tests only (csrc/fh_experimental.h): 1 = a withheld team partial, 2 = the co-residency probe says no
+HOOK_WITHHOLD_PARTIAL, HOOK_PROBE_SAYS_NO = 1, 2
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
 CREATE_RCCL_SHELL = 0x100          # or'ed into the dtype of fh_create_ex: the multi-device (RCCL) form even for a single device
@@ -61,10 +68,13 @@ SIGNATURES = {
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_fused_agree": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_coresident_probe": (_i32, [_ctx, _i32, C.POINTER(_i32)]),
     "fh_fused_shape": (_i32, [_u64, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_fwd_adj": (_i32, [_ctx, _dbl, _pd]),
     "fh_step": (_i32, [_ctx, _dbl, _pd]),
+    "fh_step_begin": (_i32, [_ctx, _dbl]),
+    "fh_step_end": (_i32, [_ctx, _pd]),
     "fh_step_accel": (_i32, [_ctx, _dbl, _dbl, _i32, _pd]),
     "fh_apply": (_i32, [_ctx, _i32, _pd, _pd]),
     "fh_comm_unique_id": (_i32, [C.c_void_p]),
@@ -76,6 +86,7 @@ SIGNATURES = {
     "fh_timing_enable": (_i32, [_ctx, _i32]),
     "fh_timing_get": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
     "fh_timing_reset": (_i32, [_ctx]),
+    "fh_timing_overlap": (_i32, [_ctx, _ctx, _i32, _pd, _pd, _pd]),
     "fh_stream_read_ms": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
 }
 
@@ -320,6 +331,13 @@ class HipContext:
         self._call("fh_fused_supported", C.byref(yes))
         return int(yes.value)
 
+    def fused_agree(self):
+        """The one-pass verdict of fused_supported() settled over the ranks of the attached communicator (any 0 wins, else any 3):
+        a COLLECTIVE call when the context has a communicator -- every rank calls it at the same point; the local query otherwise."""
+        yes = _i32(0)
+        self._call("fh_fused_agree", C.byref(yes))
+        return int(yes.value)
+
     def coresident_probe(self, workgroups):
         """True if `workgroups` whole-CU workgroups run side by side on this device (what the dense one-pass kernel needs of #CUs)."""
         ok = _i32(0)
@@ -329,6 +347,17 @@ class HipContext:
     def step(self, tau):
         """One-pass K-fwd + K-adj (no acceleration).  Raises HipTimeout if the bounded spins timed out."""
         self._call("fh_step", float(tau), self._scal_p)
+        if self._scal[15] != 0.0:
+            raise HipTimeout("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
+        return self._scal.copy()
+
+    def step_begin(self, tau):
+        """Issue step(tau) without waiting for it: the host may drive other contexts until step_end()."""
+        self._call("fh_step_begin", float(tau))
+
+    def step_end(self):
+        """Wait for the step issued by step_begin and return its scalars (HipTimeout as step())."""
+        self._call("fh_step_end", self._scal_p)
         if self._scal[15] != 0.0:
             raise HipTimeout("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()
@@ -389,6 +418,12 @@ class HipContext:
         ms, cnt = _dbl(0.0), _u64(0)
         self._call("fh_timing_get", int(kernel_id), C.byref(ms), C.byref(cnt))
         return ms.value, cnt.value
+
+    def timing_overlap(self, other, kernel_id):
+        """(ms this context's latest timed launch of `kernel_id` ran, ms `other`'s ran, ms BOTH were running; <= 0: one after the other)."""
+        a, b, both = _dbl(0.0), _dbl(0.0), _dbl(0.0)
+        _check(self.lib, self.lib.fh_timing_overlap(self._h, other._h, int(kernel_id), C.byref(a), C.byref(b), C.byref(both)))
+        return a.value, b.value, both.value
 
     def stream_read_ms(self, reps=3):
         ms, nbytes = _dbl(0.0), _u64(0)

@@ -178,7 +178,8 @@ class FBSolver:
         if self.func:                                                   # :149-151
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
-        kind = c.fused_supported() if self.fused_opt is not False else 0
+        # (fused_agree: on a context with a communicator the ranks settle on ONE verdict -- a collective call, made by every rank here)
+        kind = c.fused_agree() if self.fused_opt is not False else 0
         # How the two halves of an iteration reach the device:
         #   "always"      one-pass kernel for every launch of the loop, backtracking retries included: where it costs no more
         #                 than K-fwd alone -- the stencil, and the dense operator from n = 16384 (kind 1: 65536^2 5.0 vs 4.9 ms)

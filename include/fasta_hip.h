@@ -80,7 +80,8 @@ enum fh_scalar {
 /* FH_K_HOST_ISSUE is not a kernel: fh_timing_get reports under it the HOST time a one-pass step of the dense operator (fh_step /
  * fh_step_accel) spends issuing its launches and exchanges -- from the call's entry to the start of its one final synchronisation --
  * and the number of such calls: what one host thread pays to drive all the row blocks of a multi-device context per iteration.   */
-enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_K_FUSED = 4, FH_K_HOST_ISSUE = 5, FH_NKERNELS = 6 };
+/* FH_K_LEVEL: the clipping-level search that precedes every forward launch of the LINF / L1BALL prox kinds (csrc/fh_prox.h). */
+enum fh_kernel_id { FH_K_FWD = 0, FH_K_ADJ = 1, FH_K_AUX = 2, FH_K_COMM = 3, FH_K_FUSED = 4, FH_K_HOST_ISSUE = 5, FH_K_LEVEL = 6, FH_NKERNELS = 7 };
 
 enum fh_tuning_key {
   FH_TUNE_FWD_ROWS = 0,      /* rows per workgroup pass in K-fwd: 4, 8, 16 (0 = auto)        */
@@ -94,22 +95,15 @@ enum fh_tuning_key {
   FH_TUNE_TV_NT = 8,         /* stencil kernels: 0 = default, 1 = non-temporal loads and stores (two-launch kernels and the z-streaming
                                 one-pass kernels; the z-free one-pass sweep never loads non-temporally: its halo columns and rows are
                                 re-read through L2), 2 = non-temporal stores (the z-free sweep's default), 3 = plain accesses      */
-  FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h); bit 64 / 128: test hooks (a withheld
-                                team partial; this context's co-residency probe answers no)                                    */
-  FH_TUNE_TV_ZFREE = 10,     /* stencil one-pass steps: 1 (default) = z recomputed in flight, never read or written (40 / 56 B per
-                                pixel); 0 = the round-1 kernels that stream z (56 / 80 B per pixel)                          */
+  FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h: 2 = team members on one XCD, 4 = no
+                                sleep between polls, 8 / 16 = A/B team shapes, 32 = rows dealt cyclically); other bits are FH_E_ARG  */
+  /* key 10 (the round-1 one-pass stencil kernels that stream z) is only present in -DFH_EXPERIMENTAL builds                    */
   FH_TUNE_TV_PIPE = 11,      /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 (2 is taken as 3) = three
                                 rotating trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto   */
   FH_TUNE_TV_XCD = 12,       /* z-free one-pass stencil sweep: deal the workgroup ids out XCD by XCD, so that strips that share halo
                                 cache lines share an L2 (0 = auto = 1 = on, 2 = off: plain blockIdx order)                    */
-  FH_TUNE_TV_LDS_PAD = 13,   /* z-free one-pass stencil sweep: bytes of unused dynamic LDS per workgroup (0..65536): an occupancy
-                                limiter for experiments -- 40960 => at most 4 workgroups per CU, 53248 => 3, 65536 => 2        */
-  FH_TUNE_TV_RING = 14,      /* z-free one-pass stencil sweep: 2 or 3 = trips prefetched by LDS-DMA into a per-wave ring of that many
-                                2-row slots (loads in flight cost no registers); 1 = register-staged trips (FH_TUNE_TV_PIPE);
-                                0 = auto.  Needs an even image width, otherwise the register form runs                        */
-  FH_TUNE_TV_SLOTS = 15,     /* z-free one-pass stencil sweep, persistent form: launch at most this many workgroups per CU (1..8); each
-                                walks the chunk ids (FH_TUNE_TV_ROWS rows each, band-major) with the grid as its stride, so that the
-                                resident workgroups sweep the image as one compact moving window; 0 = one workgroup per chunk     */
+  /* keys 13-15 (occupancy limiter, LDS-DMA trip ring, persistent chunk walk of the stencil sweep: measured flat twice,
+     profiles/r04_tune_tv.txt) are only present in -DFH_EXPERIMENTAL builds (csrc/fh_experimental.h); FH_E_ARG otherwise        */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
                                 reports).  The co-residency probe then asks for that many.  Lets several one-pass grids run side by side
                                 on one device: two solves at once, partitioned devices, ranks of a row-sharded run that share a GPU
@@ -205,6 +199,12 @@ int fh_fwd_adj(fh_ctx* ctx, double tau, double* scalars);
  * fh_fused_supported: 0 = no (n > 262144, TV prox on a dense operator); 1 = dense, recommended (n >= 16384 or at least
  * 8 Mi elements); 3 = dense, available but no faster than two short launches; 2 = stencil operator (one sweep replaces both). */
 int fh_fused_supported(fh_ctx* ctx, int* yes);
+/* fh_fused_supported is a purely LOCAL query: safe to call from one rank alone.  The ranks of a row-sharded run (one process per GPU)
+ * must all take the same kind of step, so they settle on ONE verdict with fh_fused_agree: a COLLECTIVE call -- every rank of the
+ * communicator calls it at the same point (FBSolver.setup does) -- that sums the ranks' "0" and "3" verdicts; any 0 makes it 0
+ * everywhere, else any 3 makes it 3.  A rank whose local query failed still enters the exchange (contributing "0") before it
+ * returns its error, so its peers are never left waiting.  Without a communicator it equals fh_fused_supported.               */
+int fh_fused_agree(fh_ctx* ctx, int* yes);
 /* The dense one-pass kernel needs one workgroup on every compute unit at the same time.  The library checks that once per context
  * with a ~20 us probe launch (fh_fused_supported then reports 0 for the dense operator if CUs are hidden by a mask, a partition
  * mode or a co-tenant); this entry runs the same probe for `workgroups` whole-CU workgroups and reports whether they all ran side
@@ -216,6 +216,12 @@ int fh_coresident_probe(fh_ctx* ctx, int workgroups, int* ok);
  * bits; ncu: compute units (256 on MI355X).                                                                                */
 int fh_fused_shape(uint64_t n, int dtype, int variant, int ncu, int* shape5, int* instantiated);
 int fh_step(fh_ctx* ctx, double tau, double* scalars);
+/* fh_step in two halves (the loop body of fasta/__init__.py:171-188 issued now, waited for later): fh_step_begin enqueues the launch
+ * on the context's stream and returns at once; fh_step_end waits and delivers the scalar block.  In between the host may drive
+ * OTHER contexts -- two solves side by side on one device (FH_TUNE_FUSED_CUS each) from one host thread.  Every other entry point
+ * of `ctx` returns FH_E_STATE until fh_step_end has been called.                                                              */
+int fh_step_begin(fh_ctx* ctx, double tau);
+int fh_step_end(fh_ctx* ctx, double* scalars);
 /* ONE-PASS iteration with acceleration (fasta/__init__.py:220-248; dense operator, also row-sharded): as fh_step, plus
  * x1 = xprox + c*(xprox - x_accel0) and the gradient taken at z1 + c*(z1 - z_accel0) with c = coef, or 0 when restart != 0
  * and this step's restart dot <x0 - xprox, xprox - x_accel0> (:231) exceeds 1e-30; the dot is returned in FH_S_RDOT and
@@ -249,11 +255,17 @@ int fh_cu_count(fh_ctx* ctx, int* device_cus, int* one_pass_cus);
 
 /* ---- measurement: HIP-event timing of each launch on the context's stream ---------------------
  * A multi-device context reports sums over its row blocks.  When the blocks share ONE device (a repeated device id: one stream) only
- * the first block's launches carry event records and the figures are that block's scaled by the number of blocks -- two records
- * around each of the 8 x 2 launches cost more than the plumbing being measured (profiles/r04_inproc_issue.txt).                   */
+ * ONE block's launches carry event records -- the MIDDLE block's (index nblocks / 2; the first one starts on an idle device and reads
+ * high) -- and the figures are that block's scaled by the number of blocks: an ESTIMATE (row blocks may differ by one row), taken
+ * because two records around each of the 8 x 2 launches cost more than the plumbing being measured (profiles/r04_inproc_issue.txt).
+ * The sum over the blocks (FH_K_COMM) is one launch and is timed as such.                                                        */
 int fh_timing_enable(fh_ctx* ctx, int on);
 int fh_timing_get(fh_ctx* ctx, int kernel_id, double* total_ms, uint64_t* launches);
 int fh_timing_reset(fh_ctx* ctx);
+/* Did the latest timed launch of `kernel_id` on context a and on context b (plain contexts on one device, timing enabled, both
+ * waited for) run at the same time?  a_ms / b_ms: the two launches' durations; overlap_ms: how long both were running
+ * (<= 0: one had ended before the other began).  From the HIP events that bracket each launch on its own stream.              */
+int fh_timing_overlap(fh_ctx* a, fh_ctx* b, int kernel_id, double* a_ms, double* b_ms, double* overlap_ms);
 /* streaming-read ceiling: one read-only pass over the device copy of A by k_stream_probe<16,1> (csrc/fh_dense.h): one persistent
  * workgroup per CU (FH_TUNE_FWD_GRID_CAP overrides), three rotating register buffers of 16 non-temporal 16-byte loads per lane
  * (32 loads in flight behind the buffer being summed), loads + adds only; returns ms per pass.  A multi-device context

@@ -176,6 +176,78 @@ __global__ __launch_bounds__(256) void k_strip_lds(const d2* __restrict__ x, con
   wait_vm<0>();
 }
 
+// ---- (12) TILED STORAGE WITH IN-TILE HALOS (round 5: the one layout DESIGN.md 7.3 left untried) ---------------------------------
+// Every array is stored as tiles  [row band k][strip group sg][tile row t = 0 .. RB+3][wave w = 0..3][lane 0..63] : tile row t of band
+// k is image row k*RB + t - 2 (periodic), lane L of wave w of strip group sg is image column (4 sg + w) * 60 + L - 2 (periodic).  So the
+// two halo columns per side AND the two halo rows per side are stored with the tile (64/60 x (RB+4)/RB = 1.086x the bytes), every
+// wave-instruction reads ONE whole aligned 1-KiB run (x) / 512-B run (b), a workgroup's reads are one contiguous range of
+// (RB + 4) x 4 KiB that it streams front to back, and nothing is fetched from another workgroup's region.  The price is on the store
+// side: a pixel in a halo position has up to four homes, so besides its 60 owned lanes (960 B of the 1-KiB run) a wave stores lanes
+// 2,3 / 60,61 again into the neighbouring strips' halo lanes (one 4-lane store: 2 x 32 B) and, for the two rows at either end of its band,
+// all of that once more into the neighbouring band's tile.
+struct TGeo { uint32_t H, W, RB, strip_groups, bands; int xcd; };
+template <int U, int NB, int NTS, int ALU>
+__global__ __launch_bounds__(256) void k_tile(const d2* __restrict__ x, const double* __restrict__ b, d2* __restrict__ xp, const TGeo g) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wg = xcd_order(blockIdx.x, gridDim.x, g.xcd);
+  const uint32_t sg = wg % g.strip_groups, band = wg / g.strip_groups;
+  const uint32_t TR = g.RB + 4u;                                        // tile rows
+  const uint64_t tile_px = (uint64_t)TR * 256u;                          // pixels per tile (4 waves x 64 lanes per tile row)
+  const uint64_t base = ((uint64_t)band * g.strip_groups + sg) * tile_px + wave * 64u + lane;
+  const uint32_t nstrips = g.strip_groups * 4u;
+  const uint32_t strip = sg * 4u + wave;
+  // where the duplicates of this wave's edge lanes live: lanes 2,3 -> lanes 62,63 of the strip to the left; lanes 60,61 -> lanes 0,1 to the right
+  const uint32_t lstrip = (strip + nstrips - 1u) % nstrips, rstrip = (strip + 1u) % nstrips;
+  const bool own = lane >= 2u && lane < 62u;
+  const bool dupl = lane == 2u || lane == 3u, dupr = lane == 60u || lane == 61u;
+  const uint32_t dstrip = dupl ? lstrip : rstrip;
+  const uint32_t dlane = dupl ? lane + 60u : lane - 60u;
+  const uint32_t upb = (band + g.bands - 1u) % g.bands, dnb = (band + 1u) % g.bands;
+  auto tile_at = [&](uint32_t bd, uint32_t st, uint32_t t, uint32_t l) -> uint64_t {
+    return ((uint64_t)bd * g.strip_groups + st / 4u) * tile_px + (uint64_t)t * 256u + (st % 4u) * 64u + l;
+  };
+  const int total = (int)TR;
+  struct Trip { d2 x[U]; double b[U]; };
+  auto load = [&](Trip& T, int t0) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const uint64_t pix = base + (uint64_t)min(t0 + q, total - 1) * 256u;
+      T.x[q] = x[pix]; T.b[q] = b[pix];
+    }
+    asm volatile("" ::: "memory");
+  };
+  auto store = [&](const Trip& T, int t0) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int t = t0 + q;                                             // tile row; owned rows are t = 2 .. RB+1
+      const d2 v = work<ALU>(T.x[q], T.b[q]);
+      if (t >= 2 && t < (int)g.RB + 2) {
+        if (own) st<NTS>(xp + base + (uint64_t)t * 256u, v);
+        if (dupl || dupr) st<NTS>(xp + tile_at(band, dstrip, (uint32_t)t, dlane), v);
+        // the first / last two owned rows are also the halo rows RB+2, RB+3 / 0, 1 of the band above / below
+        if (t < 4 || t >= (int)g.RB) {
+          const uint32_t nb = t < 4 ? upb : dnb;
+          const uint32_t nt = t < 4 ? (uint32_t)t + g.RB : (uint32_t)t - g.RB;
+          if (own) st<NTS>(xp + tile_at(nb, strip, nt, lane), v);
+          if (dupl || dupr) st<NTS>(xp + tile_at(nb, dstrip, nt, dlane), v);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+  };
+  if constexpr (NB == 3) {
+    Trip T0, T1, T2;
+    load(T0, 0); load(T1, U);
+    for (int t0 = 0; t0 < total; t0 += 3 * U) {
+      load(T2, t0 + 2 * U); store(T0, t0);
+      load(T0, t0 + 3 * U); store(T1, t0 + U);
+      load(T1, t0 + 4 * U); store(T2, t0 + 2 * U);
+    }
+  } else {
+    for (int t0 = 0; t0 < total; t0 += U) { Trip T0; load(T0, t0); store(T0, t0); }
+  }
+}
+
 static hipEvent_t e0, e1;
 template <typename F> static int run(const char* name, double bytes, F launch) {
   launch(); CK(hipDeviceSynchronize());
@@ -337,6 +409,30 @@ int main(int argc, char** argv) {
     LSTRIP(60, 8, 1, 0, 0, 1024, 8192, 1); LSTRIP(60, 8, 1, 0, 170, 1024, 8192, 1); LSTRIP(60, 12, 1, 0, 0, 1024, 8192, 1); LSTRIP(60, 12, 1, 0, 170, 1024, 8192, 1);
     LSTRIP(60, 6, 1, 0, 0, 512, 8192, 1); LSTRIP(60, 6, 1, 0, 170, 512, 8192, 1);
     LSTRIP(60, 2, 1, 0, 0, 228, 8192, 1); LSTRIP(60, 2, 1, 0, 170, 228, 8192, 1);
+  }
+  if (set == 12) {
+    printf("=== (12) TILED storage with in-tile halo columns and rows (aligned 1-KiB reads, one contiguous range per workgroup, duplicate stores) against the\n"
+           "===      product's row-major strip walk; both capped at 5 workgroups per CU (32 KiB dynamic LDS), same grid of 35 strip groups x bands, 40*P basis\n");
+    const int CAP = 32768;
+    d2 *tx, *txp; double* tb;
+    const uint64_t tpx = (uint64_t)(H / 64 + 1) * 35 * (64 + 4) * 256;      // enough for every RB >= 64 below
+    CK(hipMalloc(&tx, tpx * 16)); CK(hipMalloc(&txp, tpx * 16)); CK(hipMalloc(&tb, tpx * 8));
+    CK(hipMemset(tx, 0, tpx * 16)); CK(hipMemset(txp, 0, tpx * 16)); CK(hipMemset(tb, 0, tpx * 8));
+#define TILE(U, NB, ALU, RB_, CAPB) do { TGeo g; g.H = H; g.W = W; g.RB = RB_; g.strip_groups = 35; g.bands = (H + RB_ - 1) / RB_; g.xcd = 1; \
+    const uint32_t grid = g.strip_groups * g.bands; \
+    if ((uint64_t)grid * (RB_ + 4) * 256 > tpx) { printf("skip RB=%d\n", RB_); break; } \
+    snprintf(name, sizeof name, "tile own=60+4 U=%d NB=%d alu=%3d rows=%3d grid=%u%s", U, NB, ALU, RB_, grid, CAPB ? " (5 wg/CU cap)" : ""); \
+    if (run(name, 40.0 * P, [&] { k_tile<U, NB, 1, ALU><<<grid, 256, CAPB>>>(tx, tb, txp, g); })) return 1; } while (0)
+#define RSTRIP(U, NB, ALU, ROWS, CAPB) do { Geo g = geo(60, ROWS, 8192, 1); const uint32_t grid = g.strip_groups * g.bands; \
+    snprintf(name, sizeof name, "reg  own=60   U=%d NB=%d alu=%3d rows=%3d grid=%u%s", U, NB, ALU, ROWS, grid, CAPB ? " (5 wg/CU cap)" : ""); \
+    if (run(name, 40.0 * P, [&] { k_strip<60, U, NB, 1, 0, ALU, 0, 4><<<grid, 256, CAPB>>>(x, b, xp, g); })) return 1; } while (0)
+    for (int rep = 0; rep < 2; ++rep) {          // twice: the second pass shows the run-to-run band on this box
+      RSTRIP(2, 1, 0, 228, CAP); TILE(2, 1, 0, 228, CAP); RSTRIP(2, 3, 0, 228, CAP); TILE(2, 3, 0, 228, CAP); TILE(4, 1, 0, 228, CAP); TILE(4, 3, 0, 228, CAP);
+      RSTRIP(2, 1, 170, 228, CAP); TILE(2, 1, 170, 228, CAP); RSTRIP(2, 3, 170, 228, CAP); TILE(2, 3, 170, 228, CAP); TILE(4, 3, 170, 228, CAP);
+    }
+    RSTRIP(2, 1, 0, 228, 0); TILE(2, 1, 0, 228, 0); TILE(2, 3, 0, 228, 0);
+    TILE(2, 1, 0, 64, CAP); TILE(2, 3, 0, 64, CAP); TILE(2, 1, 0, 128, CAP); TILE(2, 1, 170, 64, CAP); TILE(2, 1, 170, 128, CAP);
+    RSTRIP(2, 1, 240, 228, CAP); TILE(2, 1, 240, 228, CAP); TILE(2, 3, 240, 228, CAP);
   }
   return 0;
 }

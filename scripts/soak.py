@@ -74,10 +74,11 @@ def side_by_side(cus, iters):
         try:
             b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
             solver = fa.FBSolver(A, fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n), verbose=False, max_iters=iters, tolerance=0.0)
-            np.random.seed(3)
             with warnings.catch_warnings(), np.errstate(all="ignore"):
                 warnings.simplefilter("ignore")
-                solver.setup()
+                with np_seed_lock:          # setup() draws its two Lipschitz probes from the GLOBAL RNG: seed + draws must not interleave between threads
+                    np.random.seed(3)
+                    solver.setup()
                 barrier.wait()
                 t0 = time.perf_counter()
                 c = solver.run()
@@ -87,10 +88,10 @@ def side_by_side(cus, iters):
         finally:
             A.close()
     res = {}
+    np_seed_lock = threading.Lock()
     barrier = threading.Barrier(1)
     one(res, "alone")
     barrier = threading.Barrier(2)
-    np_seed_lock = threading.Lock()
     ts = [threading.Thread(target=one, args=(res, k)) for k in ("a", "b")]
     for t in ts: t.start()
     for t in ts: t.join()

@@ -137,6 +137,9 @@ class FakeContext:
     def fused_supported(self):
         return self.fused_kind
 
+    def fused_agree(self):          # (no communicator: the agreed verdict is the local one)
+        return self.fused_kind
+
     def step(self, tau):
         self.calls["step"] += 1
         self.fwd(tau)

@@ -33,7 +33,7 @@ def main():
     dev_cus, _ = op.ctx.cu_count()
     op.ctx.set_tuning(hip.TUNE_FUSED_CUS, max(32, dev_cus // grp.world // 32 * 32))
     if grp.rank == probe_no_rank:
-        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 128)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_PROBE_SAYS_NO)
     uid = grp.broadcast_bytes(hip.comm_unique_id() if grp.rank == 0 else None)
     op.ctx.comm_init(grp.world, grp.rank, uid)
     assert op.ctx.comm_count() == grp.world and op.ctx.sharded

@@ -246,7 +246,8 @@ def test_lost_partial_times_out_instead_of_hanging_and_the_solver_falls_back():
     try:
         np.random.seed(4)
         ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, backend="hip", fused=False, **opts)
-        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8 | 64)       # bit 8: the 8-member shape (n = 4096 runs without any exchange by default)
+        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8)            # bit 8: the 8-member shape (n = 4096 runs without any exchange by default)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_WITHHOLD_PARTIAL)
         c = _state(op, b, 0.02, np.zeros(n))
         t0 = time.time()
         with pytest.raises(hip.HipError):
@@ -306,7 +307,7 @@ def test_one_pass_kernel_recovers_on_the_same_context_after_a_timed_out_launch(a
         op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8)              # 8 members per team at n = 4096
         c = _state(op, b, mu, x0)
         _assert_step_matches(c, c.step(tau), refs[False], n, m)       # healthy launch first (slot parity flips)
-        op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, 2 | 8 | 64)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_WITHHOLD_PARTIAL)
         c = _state(op, b, mu, x0)
         t0 = time.time()
         with pytest.raises(hip.HipError):
@@ -314,6 +315,7 @@ def test_one_pass_kernel_recovers_on_the_same_context_after_a_timed_out_launch(a
         assert time.time() - t0 < 5.0
         variant = {"same_shape": 2 | 8, "team_of_one": 2, "other_team_count": (2 | 8) | (4 << 16)}[after]     # high half: rows-per-team floor
         op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, variant)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, 0)
         for launch in range(4):                                       # parities 0, 1, 0, 1; plain, plain, accelerated, accelerated
             accel = launch >= 2
             c = _state(op, b, mu, x0)
@@ -371,7 +373,8 @@ def test_coresidency_probe_says_yes_for_the_cus_and_no_beyond():
 def test_one_pass_kernel_on_a_capped_number_of_cus(m, n, cus):
     """FH_TUNE_FUSED_CUS: the one-pass launch (and its co-residency probe) on `cus` workgroups instead of one per CU of the device --
     what lets two one-pass grids share a device.  Same iterates and sums to rounding (the number of teams, hence the summation order, changes), plain and accelerated; and TWO contexts whose
-    caps add up to the device run their launches CONCURRENTLY on two streams without timing each other out."""
+    caps add up to the device, stepped in turn (each step() waits for its own launch, so these launches run one after the other: the
+    CONCURRENT case is test_two_capped_contexts_run_their_launches_at_the_same_time below), agree bit for bit."""
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
     b, x0 = rng.randn(m), rng.randn(n) * 0.05
@@ -393,7 +396,7 @@ def test_one_pass_kernel_on_a_capped_number_of_cus(m, n, cus):
         ref.commit(False)
         a0, a1 = ref.step_accel(tau, 0.3, True), c.step_accel(tau, 0.3, True)
         np.testing.assert_allclose(a1[:15], a0[:15], rtol=1e-10, atol=1e-18)
-        # two capped contexts, launches in flight at the same time (each context has its own stream; step() syncs only its own)
+        # two capped contexts stepped alternately (step() is synchronous: one launch at a time)
         total = ref.cu_count()[0]
         if 2 * cus <= total:
             op.ctx.set_tuning(hip.TUNE_FUSED_CUS, cus)
@@ -404,3 +407,63 @@ def test_one_pass_kernel_on_a_capped_number_of_cus(m, n, cus):
     finally:
         op.close()
         op2.close()
+
+
+def test_two_capped_contexts_run_their_launches_at_the_same_time():
+    """Two solves on ONE device, each one-pass grid capped to half of the CUs (FH_TUNE_FUSED_CUS), driven from one host thread through
+    fh_step_begin / fh_step_end: both launches are issued before either is waited for.  The HIP events that bracket each launch on its
+    own stream must show the two intervals OVERLAPPING (fh_timing_overlap) -- the test fails if the launches are serialised --, no
+    launch may time out, and every scalar block must equal, bit for bit, that of the same context stepped alone."""
+    from fasta_python_amd import synthetic
+    m, n = 8192, 16384                                  # 1 GiB per context: a launch on half the device takes ~0.3 ms
+    ops = [fa.DenseMatrixMap.synthetic(m, n, seed=5, scale=synthetic.lasso_scale(m, n)) for _ in range(2)]
+    try:
+        dev_cus = ops[0].ctx.cu_count()[0]
+        cus = dev_cus // 2 // 32 * 32
+        assert cus >= 32
+        rng = np.random.RandomState(3)
+        b, x0 = rng.randn(m), rng.randn(n) * 0.01
+        tau, mu, steps = 0.4, 0.02, 12
+        for op in ops:
+            op.ctx.set_tuning(hip.TUNE_FUSED_CUS, cus)
+
+        def fresh(op):
+            c = _state(op, b, mu, x0)
+            assert c.fused_supported() in (1, 3) and c.cu_count() == (dev_cus, cus)
+            return c
+        # each context alone: the reference bits (and a calling sequence check: begin/end == step)
+        alone = []
+        c = fresh(ops[0])
+        for _ in range(steps):
+            c.step_begin(tau)
+            with pytest.raises(hip.HipError, match="fh_step_end"):
+                c.commit(False)                                       # the context is busy until step_end
+            alone.append(c.step_end())
+            c.commit(False)
+        c = fresh(ops[0])
+        for k in range(steps):
+            assert np.array_equal(c.step(tau), alone[k])
+            c.commit(False)
+        # both at once
+        ca, cb = fresh(ops[0]), fresh(ops[1])
+        for c in (ca, cb):
+            c.timing_reset()
+            c.timing_enable(True)
+        overlaps = []
+        for k in range(steps):
+            ca.step_begin(tau)
+            cb.step_begin(tau)
+            sa, sb = ca.step_end(), cb.step_end()                     # a HipTimeout here would fail the test
+            assert np.array_equal(sa, alone[k]) and np.array_equal(sb, alone[k])
+            overlaps.append(ca.timing_overlap(cb, hip.K_FUSED))
+            ca.commit(False)
+            cb.commit(False)
+        for c in (ca, cb):
+            c.timing_enable(False)
+        frac = [both / min(a_ms, b_ms) for a_ms, b_ms, both in overlaps]
+        print("\nlaunch a / launch b / both running (ms):", [tuple(round(v, 3) for v in o) for o in overlaps[:4]], "...")
+        assert min(frac) > 0.0, f"two launches did not overlap at all: {overlaps}"
+        assert sorted(frac)[len(frac) // 2] > 0.5, f"the launches overlap for less than half of the shorter one: {overlaps}"
+    finally:
+        for op in ops:
+            op.close()

@@ -184,11 +184,19 @@ def test_tv_full_size_adjointness_8192():
         op.close()
 
 
-@pytest.mark.parametrize("zfree", [1, 0])
-@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (3, 59), (4, 60), (130, 121), (70, 500)])
-def test_one_pass_tv_step_equals_two_launch_step(H_, W_, zfree):
-    """fh_step on the stencil operator against fh_fwd + fh_adj on the same state: zfree = 1 the default kernel that
-    recomputes z in flight (k_tv_onepass), zfree = 0 the round-1 kernel that streams it (k_fused_tv_step)."""
+ONE_PASS_SHAPES = [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (3, 59), (4, 60), (130, 121), (70, 500)]
+ONE_PASS_ACCEL_SHAPES = [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (64, 1000), (130, 121)]
+
+
+@pytest.mark.parametrize("H_,W_", ONE_PASS_SHAPES)
+def test_one_pass_tv_step_equals_two_launch_step(H_, W_):
+    one_pass_tv_step_equals_two_launch_step(H_, W_, None)
+
+
+def one_pass_tv_step_equals_two_launch_step(H_, W_, zfree):
+    """fh_step on the stencil operator against fh_fwd + fh_adj on the same state.  zfree None / 1: the shipped kernel, which
+    recomputes z in flight (k_tv_onepass); 0: the round-1 kernel that streams it (k_fused_tv_step; only in the experimental
+    library: tests/test_gpu_experimental.py)."""
     rng = np.random.RandomState(H_ * 7 + W_)
     M = rng.randn(H_, W_)
     Y0 = rng.randn(H_, W_, 2) * 0.8
@@ -196,7 +204,8 @@ def test_one_pass_tv_step_equals_two_launch_step(H_, W_, zfree):
     op = fa.GradDivMap((H_, W_))
     try:
         c = op.ctx
-        c.set_tuning(hip.TUNE_TV_ZFREE, zfree)
+        if zfree is not None:
+            c.set_tuning(hip.TUNE_TV_ZFREE, zfree)
         assert c.fused_supported() == 2
 
         def fresh():
@@ -243,11 +252,14 @@ def test_tv_solve_identical_with_and_without_the_one_pass_kernel():
     np.testing.assert_allclose(a.solution, b.solution, rtol=1e-6, atol=1e-10)
 
 
-@pytest.mark.parametrize("zfree", [1, 0])
 @pytest.mark.parametrize("prox", ["tvball", "identity"])
 @pytest.mark.parametrize("restart", [True, False])
-@pytest.mark.parametrize("H_,W_", [(1, 1), (2, 3), (5, 64), (33, 61), (40, 257), (97, 130), (64, 1000), (130, 121)])
-def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox, zfree):
+@pytest.mark.parametrize("H_,W_", ONE_PASS_ACCEL_SHAPES)
+def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox):
+    one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox, None)
+
+
+def one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, prox, zfree):
     """fh_step_accel on the stencil operator (k_fused_tv_accel: both coefficient candidates in one sweep, iterate kept in
     extrapolated-on-the-fly form) in LOCKSTEP with fh_fwd + fh_adj(accel) on a second context: same alpha recursion, same
     backtracking-style retry (a launch repeated with a smaller tau before the commit), several restarts along the way.
@@ -257,7 +269,8 @@ def test_one_pass_accelerated_tv_steps_equal_two_launch_steps(H_, W_, restart, p
     Y0 = rng.randn(H_, W_, 2) * 0.8
     one, two = fa.GradDivMap((H_, W_)), fa.GradDivMap((H_, W_))
     try:
-        one.ctx.set_tuning(hip.TUNE_TV_ZFREE, zfree)
+        if zfree is not None:
+            one.ctx.set_tuning(hip.TUNE_TV_ZFREE, zfree)
         for c in (one.ctx, two.ctx):
             c.set_loss_lsq(M)
             c.set_prox(hip.PROX_TVBALL if prox == "tvball" else hip.PROX_IDENTITY)
@@ -376,33 +389,6 @@ def test_z_free_steps_can_be_followed_by_two_launch_steps():
         b.close()
 
 
-def test_zfree_switch_is_refused_while_the_accelerated_iterate_is_kept_lazily():
-    """in one-pass FISTA mode the z-free sweep rotates its image buffers without writing them, so switching
-    FH_TUNE_TV_ZFREE to 0 mid-solve would make the z-streaming kernel read stale images: the library refuses (FH_E_STATE) until
-    the next fh_init / fh_set_vector(X0); setting the value it already has stays allowed."""
-    rng = np.random.RandomState(6)
-    H_, W_ = 40, 90
-    op = fa.GradDivMap((H_, W_))
-    try:
-        c = op.ctx
-        c.set_loss_lsq(rng.randn(H_, W_))
-        c.set_prox(hip.PROX_TVBALL)
-        c.set_vector(hip.VEC_X0, rng.randn(H_, W_, 2) * 0.5)
-        c.init()
-        c.step_accel(0.2, 0.0, True)
-        c.commit(False)
-        c.set_tuning(hip.TUNE_TV_ZFREE, 1)                      # no change: fine
-        with pytest.raises(hip.HipError, match="TV_ZFREE"):
-            c.set_tuning(hip.TUNE_TV_ZFREE, 0)
-        c.step_accel(0.2, 0.3, True)                            # the solve goes on undisturbed
-        c.set_vector(hip.VEC_X0, np.zeros((H_, W_, 2)))         # a new start lifts the restriction
-        c.set_tuning(hip.TUNE_TV_ZFREE, 0)
-        c.init()
-        c.step_accel(0.2, 0.0, True)
-    finally:
-        op.close()
-
-
 @pytest.mark.parametrize("H_,W_,seed", [(32, 32, 21), (64, 80, 22)])
 def test_tv_adaptive_runs_to_convergence_and_the_first_divergence_from_the_oracle_is_late(H_, W_, seed, capsys):
     """Adaptive FBS on the TV dual backtracks every few iterations and is sensitive to the last digit of its sums: the oracle run
@@ -441,46 +427,15 @@ def test_tv_adaptive_runs_to_convergence_and_the_first_divergence_from_the_oracl
     np.testing.assert_allclose(pr.tv_primal(M, mu, got.solution), pr.tv_primal(M, mu, want.solution), atol=2e-2)
 
 
-@pytest.mark.parametrize("ring,slots,rows", [(2, 0, 0), (3, 0, 0), (1, 2, 16), (2, 3, 8), (1, 1, 4), (2, 5, 32)])
-@pytest.mark.parametrize("H_,W_", [(2, 4), (5, 64), (33, 62), (40, 258), (97, 130), (64, 1000), (130, 122), (300, 4000), (37, 61)])
-def test_ring_and_persistent_forms_of_the_one_pass_sweep_equal_the_default(H_, W_, ring, slots, rows):
-    """Round 4: FH_TUNE_TV_RING (2-row trips prefetched by LDS-DMA into a per-wave ring; needs an even width -- an odd one runs the
-    register form) and FH_TUNE_TV_SLOTS (persistent workgroups walking short chunks) change how the sweep's bytes arrive and which
-    workgroup sums what, never a stored value: xprox must be BIT-identical to the default sweep's, the sums equal to rounding -- plain
-    and accelerated steps, with and without a lagging extrapolation coefficient."""
-    rng = np.random.RandomState(H_ * 11 + W_)
-    M = rng.randn(H_, W_)
-    Y0 = rng.randn(H_, W_, 2) * 0.8
-    tau = 0.11
-    op = fa.GradDivMap((H_, W_))
+def test_experimental_stencil_keys_are_refused_by_the_shipped_library():
+    """round 5: the forms of the stencil sweep that measured flat twice (LDS-DMA ring, persistent chunk walk, occupancy limiter) and the
+    superseded z-streaming one-pass kernels are compiled only into libfasta_hip_experimental.so; the shipped library names the reason."""
+    if "experimental" in os.path.basename(hip.LIB_PATH):
+        return                                          # (a run of this file against the experimental library: nothing to refuse)
+    op = fa.GradDivMap((8, 8))
     try:
-        c = op.ctx
-
-        def signature():
-            c.set_loss_lsq(M)
-            c.set_prox(hip.PROX_TVBALL)
-            c.set_vector(hip.VEC_X0, Y0)
-            c.init()
-            s = c.step(tau)
-            xp = c.get_vector(hip.VEC_XPROX, Y0.size)
-            c.set_vector(hip.VEC_X0, Y0)
-            c.init()
-            a1 = c.step_accel(tau, 0.0, True)
-            c.commit(False)
-            a2 = c.step_accel(tau, 0.3, False)          # reads both prox outputs (lagging coefficient of the previous step)
-            c.commit(False)
-            a3 = c.step_accel(tau, 0.45, True)
-            xa = c.get_vector(hip.VEC_XPROX, Y0.size)
-            return s, xp, a1, a2, a3, xa
-        for key, v in ((hip.TUNE_TV_RING, 1), (hip.TUNE_TV_SLOTS, 0), (hip.TUNE_TV_ROWS, 0)):
-            c.set_tuning(key, v)
-        ref = signature()
-        for key, v in ((hip.TUNE_TV_RING, ring), (hip.TUNE_TV_SLOTS, slots), (hip.TUNE_TV_ROWS, rows)):
-            c.set_tuning(key, v)
-        got = signature()
-        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[5], ref[5])
-        for g, r in ((got[0], ref[0]), (got[2], ref[2]), (got[3], ref[3]), (got[4], ref[4])):
-            np.testing.assert_allclose(g, r, rtol=1e-11, atol=1e-300)
-        assert np.array_equal(signature()[0], got[0])                 # and the chosen form is bitwise repeatable
+        for key in hip.EXPERIMENTAL_KEYS:
+            with pytest.raises(hip.HipError, match="experimental"):
+                op.ctx.set_tuning(key, 1)
     finally:
         op.close()
