@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="one-pass iteration kernel (fh_step): auto = when the shape supports it")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="device storage of A: f64 (default, the headline) or f32 (opt-in throughput mode; arithmetic stays float64)")
+    ap.add_argument("--preflight-only", action="store_true",
+                    help="run the multi-GPU preflight (fasta_python_amd/preflight.py: devices, RCCL, communicator, two checked all-reduces, "
+                         "co-residency probe, ranks_seen) and stop; `--gpus N` always runs it first")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="rendezvous, broadcast, barrier and max-over-ranks only -- no GPU work (CPU rehearsal of --gpus N)")
     ap.add_argument("--inproc", action="store_true",
@@ -698,6 +701,18 @@ def main(argv=None):
     ranks_on_my_device = len([r for r in range(grp.world) if r % ndev == grp.local_rank % ndev]) if grp.world > ndev else 1
     grp.local_rank = grp.local_rank % ndev
     fused = FUSED_OPT[args.fused]
+    # ---- multi-GPU preflight: before anything large is allocated, its verdict is the first thing on stderr -------------------------
+    if args.gpus > 1 or grp.force or args.preflight_only:
+        from fasta_python_amd import preflight
+        if args.inproc:
+            line = preflight.inproc_check([int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus)), args.n)
+        else:
+            share = max(32, hip.device_cus(grp.local_rank) // ranks_on_my_device // 32 * 32) if ranks_on_my_device > 1 else 0
+            line = preflight.rank_check(grp, args.n, share, quiet_stdout)
+        if grp.rank == 0:
+            print(line, file=sys.stderr, flush=True)
+        if args.preflight_only:
+            return grp.close()
     if args.workload == "tv":
         if grp.world != 1:
             raise SystemExit("the TV workload is single-GPU (BASELINE config 4)")

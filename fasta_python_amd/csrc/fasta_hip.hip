@@ -4,6 +4,7 @@
 // plus RCCL (dlopen'ed on first use) for the row-sharded adjoint.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -18,6 +19,7 @@
 #include "fh_tv.h"
 #include "fh_prox.h"
 #include "fh_fused.h"
+#include "fh_setup.h"
 
 // The one-pass kernel's variants: ONE table, fh_fused_instances.inc, drives (a) the explicit instantiations, compiled in four
 // parallel groups by fh_fused_part.hip, (b) their `extern template` declarations here and (c) the host dispatch table kFusedTable
@@ -49,6 +51,25 @@ static const FusedEntry kFusedTable[] = {
 #undef FUSED_INST_1
 #undef FUSED_INST_2
 #undef FUSED_INST_3
+
+// the three-column set-up kernel's variants: the same scheme, fh_setup_instances.inc / fh_setup_part.hip
+#ifndef FH_SINGLE_TU
+#define FH_SETUP_DECLARE(P, PI, T, NT, NR) extern template __global__ void k_setup_dense<P, PI, T, NT, NR>(const SetupP);
+#define SETUP_INST_0 FH_SETUP_DECLARE
+#define SETUP_INST_1 FH_SETUP_DECLARE
+#include "fh_setup_instances.inc"
+#undef SETUP_INST_0
+#undef SETUP_INST_1
+#endif
+struct SetupEntry { int ppt, pipe, team, threads, nr; void (*kernel)(const SetupP); };
+#define FH_SETUP_ROW(P, PI, T, NT, NR) {P, PI, T, NT, NR, k_setup_dense<P, PI, T, NT, NR>},
+#define SETUP_INST_0 FH_SETUP_ROW
+#define SETUP_INST_1 FH_SETUP_ROW
+static const SetupEntry kSetupTable[] = {
+#include "fh_setup_instances.inc"
+};
+#undef SETUP_INST_0
+#undef SETUP_INST_1
 
 #include "fh_host_ctx.h"
 #include "fh_host_launch.h"
@@ -188,6 +209,8 @@ extern "C" int fh_destroy(fh_ctx* c) {
   c->owner = nullptr;
   (void)fh_comm_destroy(c);
   free_operator(c);
+  if (c->lvl_rec) (void)hipFree(c->lvl_rec);
+  if (c->lvl_cnt) (void)hipFree(c->lvl_cnt);
   if (c->counters) (void)hipFree(c->counters);
   if (c->dscal) (void)hipFree(c->dscal);
   if (c->hscal) (void)hipHostFree(c->hscal);
@@ -565,6 +588,96 @@ extern "C" int fh_init(fh_ctx* c, double* scalars) {
   return fetch_scalars(c, scalars);
 }
 
+// The solver's whole set-up (fasta/__init__.py:100-113 and :135-137) in ONE call: the two Lipschitz probes live in FH_VEC_T0 / FH_VEC_T1,
+// x0 in FH_VEC_X0.  Leaves the state fh_init leaves (z, g0, best iterate, acceleration history) and returns fh_init's scalars plus
+// FH_S_DG2 = ||A^H grad f(A T0) - A^H grad f(A T1)||^2 and FH_S_DX2 = ||T0 - T1||^2 (the two norms of :110); FH_VEC_T2 / FH_VEC_T3 are
+// scratch afterwards (the one-read kernel forms the gradient difference as A^T A (T0 - T1): csrc/fh_setup.h).
+// Where the three-column kernel of csrc/fh_setup.h has a shape for this operator (dense float64, least squares, n <= 65536, single context, large
+// enough for the one-pass kernel to pay) all of it comes from ONE read of A; everywhere else -- and after a hand-off timeout -- it is
+// the three passes fh_gradient_at x 2 + fh_init, so the call is always available and its results agree to summation-order rounding
+// (bit for bit where the one-pass kernel serves the three passes too).
+static int launch_setup_dense(fh_ctx* c, bool* launched) {
+  *launched = false;
+  if (c->op != OP_DENSE || c->f32 || c->loss_kind != LOSS_LSQ || row_sharded(c) || !c->shards.empty() || !fused_pays(c)) return 0;
+  const FusedShape sh = fused_shape(c);
+  if (!sh.ppt || sh.xlds) return 0;
+  const SetupEntry* e = nullptr;
+  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) { e = &k; break; }
+  if (!e || !co_resident(c)) return 0;
+  SetupP p;
+  p.A = c->A; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.ldp = (uint32_t)(c->ld / 2); p.nv2 = p.ld2;
+  p.nteams = (uint32_t)(fused_ncu(c) / sh.team);
+  if (c->fused_min_rows > 0) {
+    const uint64_t want = std::max<uint64_t>(8, round_up((c->mp + c->fused_min_rows - 1) / c->fused_min_rows, 8));
+    p.nteams = (uint32_t)std::min<uint64_t>(p.nteams, want);
+  }
+  p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
+  p.x[0] = c->T[0]; p.x[1] = c->T[1]; p.x[2] = c->X[c->xi];
+  p.g[0] = c->T[2]; p.g[1] = c->T[3]; p.g[2] = c->G[c->gc];
+  p.z = c->Z[c->zc]; p.b = c->b;
+  const unsigned grid = p.nteams * sh.team;
+  const size_t sl = sh.team < 8 ? 8 : sh.team;
+  const size_t slots_elems = (size_t)c->mp * e->nr * sl;
+  const size_t gpart_elems = (size_t)p.nteams * e->nr * p.nv2 * 2;
+  FH_TRY(ensure_ws(c, (gpart_elems + (size_t)grid * 8) * sizeof(double)));
+  p.gpart = c->ws; p.red = p.gpart + gpart_elems;
+  if (slots_elems * sizeof(double) > c->slotbuf_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->slotbuf) { HIP_TRY(hipFree(c->slotbuf)); c->slotbuf = nullptr; c->slotbuf_bytes = 0; }
+    const size_t bytes = round_up(slots_elems * sizeof(double), 1 << 20);
+    HIP_TRY(hipMalloc((void**)&c->slotbuf, bytes));
+    c->slotbuf_bytes = bytes;
+  }
+  c->slots_sig = 0;                       // the step kernel's two slot arrays share this buffer: it refills them on its next launch
+  p.slots = c->slotbuf;
+  if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
+  HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
+  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
+  p.out = scalar_out(c);
+  t_begin(c, FH_K_FUSED);
+  e->kernel<<<dim3(grid), dim3(e->threads), 0, c->stream>>>(p);
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
+  *launched = true;
+  return 0;
+}
+
+static int diff_norm_sq(fh_ctx* c, int vec_a, int vec_b, double* sumsq);
+extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec);
+extern "C" int fh_setup(fh_ctx* c, double* scalars) {
+  FH_TRY(check_ready(c, true));
+  if (!scalars) return fail(FH_E_ARG, "fh_setup: null scalars");
+  if (c->shards.empty()) {
+    bool launched = false;
+    FH_TRY(use_device(c));
+    FH_TRY(launch_setup_dense(c, &launched));
+    if (launched) {
+      // what fh_init does besides its pass over A (fasta/__init__.py:154-167), behind the one launch, under one synchronisation
+      c->lazy = false; c->commits = 0; c->tvz_pending = false; c->zcur_stale = false;
+      double* x0 = c->X[c->xi];
+      HIP_TRY(hipMemcpyAsync(c->P[c->pc], x0, c->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      c->bi = c->xi;
+      for (int q = 0; q < 3; ++q) if (q != c->xi) { c->ti = q; break; }
+      c->last_accel = false;
+      FH_TRY(launch_gterms(c, x0));
+      FH_TRY(fetch_scalars(c, scalars));
+      if (scalars[15] == 0.0) return 0;
+      c->slots_sig = 0;                   // a hand-off timed out (results invalid): the three passes below redo everything
+    }
+  }
+  double dg2 = 0.0, dx2 = 0.0;
+  FH_TRY(fh_gradient_at(c, FH_VEC_T0, FH_VEC_T2));
+  FH_TRY(fh_gradient_at(c, FH_VEC_T1, FH_VEC_T3));
+  FH_TRY(diff_norm_sq(c, FH_VEC_T2, FH_VEC_T3, &dg2));
+  FH_TRY(diff_norm_sq(c, FH_VEC_T0, FH_VEC_T1, &dx2));
+  FH_TRY(fh_init(c, scalars));
+  scalars[FH_S_DG2] = dg2;
+  scalars[FH_S_DX2] = dx2;
+  return 0;
+}
+
 extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec) {
   FH_TRY(check_ready(c, true));
   const int ns = nshards(c);
@@ -588,12 +701,13 @@ extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec) {
   return finish(c);
 }
 
-extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
+// sum of (a_i - b_i)^2 of two device vectors of equal length
+static int diff_norm_sq(fh_ctx* c, int vec_a, int vec_b, double* sumsq) {
   FH_TRY(check_ready(c, false));
-  if (!out) return fail(FH_E_ARG, "null out");
+  if (!sumsq) return fail(FH_E_ARG, "null out");
   if (!c->shards.empty()) {                        // n-side vectors are replicated: any shard has the answer
     if (m_side(vec_a) || m_side(vec_b)) return fail(FH_E_ARG, "fh_diff_norm on a multi-device context takes n-side vectors");
-    return fh_diff_norm(c->shards[0], vec_a, vec_b, out);
+    return diff_norm_sq(c->shards[0], vec_a, vec_b, sumsq);
   }
   uint64_t l1 = 0, l2 = 0;
   double* a = vec_ptr(c, vec_a, &l1);
@@ -605,7 +719,14 @@ extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->hscal + FH_NSCALARS + 1, c->dscal + FH_NSCALARS + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   FH_TRY(finish(c));
-  *out = sqrt(c->hscal[FH_NSCALARS + 1]);
+  *sumsq = c->hscal[FH_NSCALARS + 1];
+  return 0;
+}
+extern "C" int fh_diff_norm(fh_ctx* c, int vec_a, int vec_b, double* out) {
+  if (!out) return fail(FH_E_ARG, "null out");
+  double sumsq = 0.0;
+  FH_TRY(diff_norm_sq(c, vec_a, vec_b, &sumsq));
+  *out = sqrt(sumsq);
   return 0;
 }
 
@@ -936,6 +1057,60 @@ extern "C" int fh_comm_count(fh_ctx* c, int* nranks) {
     c = c->shards[0];
   }
   if (c->comm) NCCL_TRY(g_rccl.CommCount(c->comm, nranks));   // what RCCL itself reports, not what the caller asked for
+  return 0;
+}
+
+// RCCL's version code (ncclGetVersion), or -1 when the loaded library does not export it / none is loaded yet
+extern "C" int fh_comm_version(int* version) {
+  if (!version) return fail(FH_E_ARG, "null argument");
+  *version = -1;
+  if (g_rccl.lib && g_rccl.GetVersion) { int v = 0; if (g_rccl.GetVersion(&v) == 0) *version = v; }
+  return 0;
+}
+
+// The exchange of this context -- the all-reduce of a rank's communicator, the grouped all-reduce or the in-library sum of a
+// multi-device context -- run on a KNOWN pattern and checked against its closed form: row block r (0-based) contributes
+// (r + 1) * (i mod 1021 + 1) at index i, so the sum over N blocks must be N (N + 1) / 2 * (i mod 1021 + 1) exactly.
+// Collective on a context with a communicator (every rank calls it with the same count).  For the multi-GPU preflight
+// (fasta_python_amd/preflight.py): the first contact with RCCL happens on a few KiB, not behind a 16-GiB allocation.
+static __global__ void k_selftest_fill(double* v, uint64_t count, double rank1) {
+  for (uint64_t i = (uint64_t)blockIdx.x * FH_WG + threadIdx.x; i < count; i += (uint64_t)gridDim.x * FH_WG) v[i] = rank1 * (double)(i % 1021u + 1u);
+}
+extern "C" int fh_comm_selftest(fh_ctx* c, uint64_t count, double* max_abs_err, int* nblocks) {
+  if (!c || !max_abs_err || count == 0 || count > ((uint64_t)1 << 26)) return fail(FH_E_ARG, "fh_comm_selftest: bad argument");
+  if (c->pending_step) return fail(FH_E_STATE, "a step issued by fh_step_begin is still in flight on this context");
+  const int ns = nshards(c);
+  const bool shell = !c->shards.empty();
+  const int N = shell ? ns : (c->comm ? c->nranks : 1);
+  int rc = 0;
+  for (int k = 0; k < ns && rc == 0; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    rc = use_device(s);
+    if (rc == 0 && hipMalloc((void**)&s->selftest_buf, count * sizeof(double)) != hipSuccess) rc = fail(FH_E_STATE, "fh_comm_selftest: hipMalloc of %llu doubles failed", (unsigned long long)count);
+    if (rc == 0) {
+      const unsigned grid = (unsigned)std::min<uint64_t>((count + FH_WG - 1) / FH_WG, 1024);
+      k_selftest_fill<<<dim3(grid), dim3(FH_WG), 0, s->stream>>>(s->selftest_buf, count, (double)((shell ? k : s->rank) + 1));
+      if (hipGetLastError() != hipSuccess) rc = fail(FH_E_STATE, "fh_comm_selftest: fill launch failed");
+    }
+  }
+  // (a rank that failed locally still enters the exchange when it can: its peers must not be left waiting)
+  const bool can_exchange = [&] { for (int k = 0; k < ns; ++k) if (!shard_of(c, k)->selftest_buf) return false; return true; }();
+  if (can_exchange) { const int rs = sum_over_shards(c, [](fh_ctx* s) { return s->selftest_buf; }, (size_t)count); if (rc == 0) rc = rs; }
+  double worst = 0.0;
+  std::vector<double> host(rc == 0 ? count : 0);
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    (void)hipSetDevice(s->device);
+    if (rc == 0) {
+      if (hipMemcpyAsync(host.data(), s->selftest_buf, count * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+          hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(FH_E_STATE, "fh_comm_selftest: reading the result back failed");
+      else for (uint64_t i = 0; i < count; ++i) worst = std::max(worst, fabs(host[i] - 0.5 * N * (N + 1) * (double)(i % 1021u + 1u)));
+    }
+    if (s->selftest_buf) { (void)hipStreamSynchronize(s->stream); (void)hipFree(s->selftest_buf); s->selftest_buf = nullptr; }
+  }
+  if (rc != 0) return rc;
+  *max_abs_err = worst;
+  if (nblocks) *nblocks = N;
   return 0;
 }
 

@@ -47,6 +47,7 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, fh_nccl_comm, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*GetVersion)(int*) = nullptr;          // optional (diagnostics only)
   const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -81,6 +82,7 @@ static int rccl_load() {
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  *(void**)(&g_rccl.GetVersion) = dlsym(g_rccl.lib, "ncclGetVersion");
   return 0;
 }
 #define NCCL_TRY(expr)                                                                        \
@@ -202,6 +204,9 @@ struct fh_ctx {
   std::vector<fh_ctx*> shards;       // non-empty: this context is a shell
   std::vector<uint64_t> shard_row0;  // first row of every shard, plus the total (size shards + 1)
   fh_ctx* owner = nullptr;           // set in a shard
+  double* lvl_rec = nullptr;         // multi-workgroup level search: per-pass records and counters (allocated on first use, counters kept zero)
+  unsigned* lvl_cnt = nullptr;
+  double* selftest_buf = nullptr;    // fh_comm_selftest's scratch (freed before it returns)
   bool pending_step = false;         // fh_step_begin has issued a step whose fh_step_end is still to come (every other entry point refuses)
   bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)
   bool owns_stream = true;           // false in shards 1.. of an emulated group (they run on shard 0's stream)

@@ -166,6 +166,20 @@ static int launch_level_search(fh_ctx* c, double tau) {
   const double* g0 = c->G[c->gc];
   double* out = c->dscal + FH_NSCALARS;
   const uint32_t n = (uint32_t)c->n;
+  if (n > 16u * LVL_WG && n <= (uint32_t)LVL_MAXG * LVL_MEPT * LVL_WG) {      // several workgroups, LVL_MEPT values per thread (csrc/fh_prox.h)
+    if (!c->lvl_rec) {
+      HIP_TRY(hipMalloc((void**)&c->lvl_rec, (size_t)LVL_MAXPASS * LVL_MAXG * 2 * sizeof(double)));
+      HIP_TRY(hipMalloc((void**)&c->lvl_cnt, (LVL_MAXPASS + 1) * sizeof(unsigned)));
+      HIP_TRY(hipMemsetAsync(c->lvl_cnt, 0, (LVL_MAXPASS + 1) * sizeof(unsigned), c->stream));
+    }
+    LevelWs ws = {c->lvl_rec, c->lvl_cnt};
+    const unsigned G = (n + LVL_MEPT * LVL_WG - 1) / (LVL_MEPT * LVL_WG);
+    t_begin(c, FH_K_LEVEL);
+    k_level_search_multi<<<dim3(G), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out, ws);
+    t_end(c, FH_K_LEVEL);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   t_begin(c, FH_K_LEVEL);
   if (n <= 1u * LVL_WG) k_level_search<1><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 4u * LVL_WG) k_level_search<4><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "fh_set_vector": (_i32, [_ctx, _i32, _pd, _u64]),
     "fh_get_vector": (_i32, [_ctx, _i32, _pd, _u64]),
     "fh_init": (_i32, [_ctx, _pd]),
+    "fh_setup": (_i32, [_ctx, _pd]),
     "fh_gradient_at": (_i32, [_ctx, _i32, _i32]),
     "fh_diff_norm": (_i32, [_ctx, _i32, _i32, _pd]),
     "fh_fwd": (_i32, [_ctx, _dbl, _pd]),
@@ -82,6 +83,8 @@ SIGNATURES = {
     "fh_comm_count": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_comm_destroy": (_i32, [_ctx]),
     "fh_comm_library": (C.c_char_p, []),
+    "fh_comm_version": (_i32, [C.POINTER(_i32)]),
+    "fh_comm_selftest": (_i32, [_ctx, _u64, _pd, C.POINTER(_i32)]),
     "fh_cu_count": (_i32, [_ctx, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_timing_enable": (_i32, [_ctx, _i32]),
     "fh_timing_get": (_i32, [_ctx, _i32, _pd, C.POINTER(_u64)]),
@@ -156,6 +159,14 @@ def fused_shape(n, storage="f64", variant=2, ncu=256):
 def comm_library():
     """Path of the library the collectives come from ("" before the first communicator): the system's RCCL or $FASTA_RCCL_LIB."""
     return load_library().fh_comm_library().decode(errors="replace")
+
+
+def comm_version():
+    """RCCL's version code (e.g. 22203), or -1 before the first communicator / when the loaded library does not export it."""
+    lib = load_library()
+    v = _i32(-1)
+    _check(lib, lib.fh_comm_version(C.byref(v)))
+    return int(v.value)
 
 
 def comm_unique_id():
@@ -303,6 +314,12 @@ class HipContext:
         self._call("fh_init", self._scal_p)
         return self._scal.copy()
 
+    def setup(self):
+        """fh_setup: the two Lipschitz probes (in VEC_T0 / VEC_T1) and init() in one call -- one read of a dense least-squares A where the
+        one-read kernel has a shape.  Scalars as init(), plus S_DG2 = ||grad(T0) - grad(T1)||^2 and S_DX2 = ||T0 - T1||^2 (VEC_T2 / T3: scratch)."""
+        self._call("fh_setup", self._scal_p)
+        return self._scal.copy()
+
     def gradient_at(self, src, dst):
         self._call("fh_gradient_at", int(src), int(dst))
 
@@ -396,6 +413,12 @@ class HipContext:
         n = _i32(0)
         self._call("fh_comm_count", C.byref(n))
         return int(n.value)
+
+    def comm_selftest(self, count):
+        """(max |error|, blocks summed over) of this context's exchange on a known pattern of `count` doubles (collective with a communicator)."""
+        err, nb = _dbl(-1.0), _i32(0)
+        self._call("fh_comm_selftest", int(count), C.byref(err), C.byref(nb))
+        return err.value, int(nb.value)
 
     def comm_destroy(self):
         self._call("fh_comm_destroy")

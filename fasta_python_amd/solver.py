@@ -139,15 +139,25 @@ class FBSolver:
         self._fval = fval
         c.set_prox(self.prox.kind, self.prox.mu, self.prox.lo, self.prox.hi)
         L, tau0 = self.L, self.tau0
-        if not L or not tau0:                                           # :100-113
+        probes = not L or not tau0
+        if probes:                                                      # :100-113
             p1 = np.random.randn(*self.shape)                           # same two global-RNG draws
             p2 = np.random.randn(*self.shape)
             c.set_vector(hip.VEC_T0, p1)
             c.set_vector(hip.VEC_T1, p2)
-            c.gradient_at(hip.VEC_T0, hip.VEC_T2)
-            c.gradient_at(hip.VEC_T1, hip.VEC_T3)
-            L = np.float64(c.diff_norm(hip.VEC_T2, hip.VEC_T3)) / np.float64(c.diff_norm(hip.VEC_T0, hip.VEC_T1))
+        c.set_vector(hip.VEC_X0, self.x0)
+        if probes and hasattr(c, "setup"):
+            # probes and the initial pass (:135-137) in ONE call: one read of a dense A where the three-column kernel has a shape
+            s = c.setup()
+            L = _sqrt(s[hip.S_DG2]) / _sqrt(s[hip.S_DX2])
             tau0 = (2 / L) / 10
+        else:
+            if probes:
+                c.gradient_at(hip.VEC_T0, hip.VEC_T2)
+                c.gradient_at(hip.VEC_T1, hip.VEC_T3)
+                L = np.float64(c.diff_norm(hip.VEC_T2, hip.VEC_T3)) / np.float64(c.diff_norm(hip.VEC_T0, hip.VEC_T1))
+                tau0 = (2 / L) / 10
+            s = c.init()                                                # :135-137
         if not tau0:                                                    # :115-116
             tau0 = 1 / L
         self.L, self.tau0 = L, tau0
@@ -164,8 +174,6 @@ class FBSolver:
         self.times = np.zeros(K + 1)
         self.total_backtracks = 0
 
-        c.set_vector(hip.VEC_X0, self.x0)
-        s = c.init()                                                    # :135-137
         f1 = fval(s[hip.S_FSQ])
         self.f_hist[0] = f1
         self.objectives = self.iterates = self.function_hist = None
@@ -178,7 +186,6 @@ class FBSolver:
         if self.func:                                                   # :149-151
             self.function_hist = np.zeros(K + 1)
             self.function_hist[0] = self.func(self.x0)
-        # (fused_agree: on a context with a communicator the ranks settle on ONE verdict -- a collective call, made by every rank here)
         kind = c.fused_agree() if self.fused_opt is not False else 0
         # How the two halves of an iteration reach the device:
         #   "always"      one-pass kernel for every launch of the loop, backtracking retries included: where it costs no more

@@ -177,6 +177,14 @@ int fh_get_vector(fh_ctx* ctx, int which, double* host, uint64_t len);
 /* fasta/__init__.py:132-137: z1 = A x0, f1 = f(z1), g0 = A^H grad f(z1); arms the acceleration
  * state (x_accel1 = x0, z_accel1 = z1, :154-157).  scalars: FH_S_FSQ, FH_S_GSUM, FH_S_GMAX.       */
 int fh_init(fh_ctx* ctx, double* scalars);
+/* The whole set-up of a solve in one call (fasta/__init__.py:100-113 Lipschitz probes + :135-137 initial pass): with the two probes
+ * in FH_VEC_T0 / FH_VEC_T1 and x0 in FH_VEC_X0 it leaves the state fh_init leaves and returns fh_init's scalars plus
+ * FH_S_DG2 = ||A^H grad f(A T0) - A^H grad f(A T1)||^2 and FH_S_DX2 = ||T0 - T1||^2 (L = sqrt of their quotient, :110).
+ * FH_VEC_T2 / FH_VEC_T3 are scratch afterwards.  A dense float64 least-squares operator with n <= 65536 on a single-device context
+ * is read ONCE for the whole set-up (csrc/fh_setup.h: two dot products and two rank-1 updates per row buffer -- x0, and the probes'
+ * difference, since grad(T0) - grad(T1) = A^T A (T0 - T1) there); every other operator takes the three passes fh_gradient_at x 2 +
+ * fh_init inside the call.  z, f, g0 are bit-identical either way; the norm of the gradient difference agrees to ~1e-15 relative.  */
+int fh_setup(fh_ctx* ctx, double* scalars);
 /* dst = A^H grad f(A src) for n-length device vectors (Lipschitz probes, fasta/__init__.py:106-107) */
 int fh_gradient_at(fh_ctx* ctx, int src_vec, int dst_vec);
 /* ||a - b||_2 of two n-length device vectors (fasta/__init__.py:110)                             */
@@ -247,6 +255,13 @@ int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
 /* ranks of the attached communicator as RCCL reports them (ncclCommCount); 1 without a communicator */
 int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
+/* RCCL's version code as ncclGetVersion reports it; -1 when no library is loaded yet or it does not export the symbol           */
+int fh_comm_version(int* version);
+/* The context's exchange (the rank's all-reduce, or a multi-device context's grouped all-reduce / in-library sum) on a known
+ * pattern of `count` doubles, checked against its closed-form sum: max_abs_err must come back 0, nblocks = the ranks / row blocks
+ * summed over.  COLLECTIVE on a context with a communicator.  The multi-GPU preflight's first contact with RCCL
+ * (fasta_python_amd/preflight.py); the op being sharded is `A.T @ x`, fasta/linalg.py:41.                                      */
+int fh_comm_selftest(fh_ctx* ctx, uint64_t count, double* max_abs_err, int* nblocks);
 /* path of the library the collectives' entry points were taken from: the system's RCCL, or what $FASTA_RCCL_LIB names (a
  * substitution is also announced once on stderr); "" before the first communicator                                         */
 const char* fh_comm_library(void);

@@ -168,6 +168,49 @@ def test_bench_two_real_ranks_at_the_config5_shard_shape(mock_rccl):
     assert out["roofline"]["fused_one_pass_steps"] == 4 and out["roofline"]["comm_launches"] == 4      # one exchange per iteration, no fall-back
 
 
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FASTA_BENCH_RDV",
+                                                            "FASTA_BENCH_TOKEN", "FASTA_BENCH_FORCE_DIST")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_preflight_with_several_real_ranks(mock_rccl, world):
+    """round 5: `bench.py --gpus N` meets RCCL on a few KiB first (fasta_python_amd/preflight.py): device count, library + version,
+    communicator over N ranks, all-reduces of 128 and n + 3 doubles against their closed forms, co-residency probe, ranks_seen == N.
+    Here with N real rank processes on the one GPU (the stand-in library in RCCL's place); the verdict is the first line on stderr."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--launcher", "socket", "--preflight-only"],
+                         capture_output=True, text=True, timeout=300, env=_clean_env(FASTA_RCCL_LIB=mock_rccl), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    ok = [ln for ln in res.stderr.splitlines() if ln.startswith("fasta preflight")]
+    assert len(ok) == 1 and ok[0].startswith(f"fasta preflight ok: {world} rank(s)") and f"ranks_seen {world}" in ok[0] and mock_rccl in ok[0], res.stderr[-3000:]
+    assert res.stdout.strip() == ""
+
+
+def test_preflight_with_one_rank_on_real_rccl():
+    """`python -m fasta_python_amd.preflight 1`: a one-rank communicator on the system's RCCL -- the library, its version and the two
+    checked all-reduces are the real thing."""
+    res = subprocess.run([sys.executable, "-m", "fasta_python_amd.preflight", "1"], capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    ok = [ln for ln in res.stderr.splitlines() if ln.startswith("fasta preflight")]
+    assert len(ok) == 1 and "ok: 1 rank(s)" in ok[0] and "librccl" in ok[0] and "version -1" not in ok[0], res.stderr[-3000:]
+
+
+def test_preflight_of_the_in_process_form_and_its_failure_line():
+    """The in-process form on the one GPU (`--devices 0,0,0`: three row blocks, sums by the in-library kernel, and the 256 x 4096 solve
+    against the single-device one); and a device that does not exist: ONE line naming the step, exit status 3, nothing on stdout."""
+    res = subprocess.run([sys.executable, "-m", "fasta_python_amd.preflight", "3", "--inproc", "--devices", "0,0,0"], capture_output=True, text=True,
+                         timeout=300, env=_clean_env(), cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "fasta preflight ok: 1 process x 3 row block(s)" in res.stderr and "equals the single-device solve" in res.stderr
+    res = subprocess.run([sys.executable, "-m", "fasta_python_amd.preflight", "2", "--inproc", "--devices", "0,63"], capture_output=True, text=True,
+                         timeout=300, env=_clean_env(), cwd=ROOT)
+    lines = [ln for ln in res.stderr.splitlines() if ln.startswith("fasta preflight")]
+    assert res.returncode == 3 and len(lines) == 1 and lines[0].startswith("fasta preflight FAILED at step 'device count'"), res.stderr[-3000:]
+    assert res.stdout.strip() == ""
+
+
 INPROC_RCCL = r"""
 import json, sys, warnings
 import numpy as np

@@ -55,6 +55,30 @@ def test_level_search_equals_sort_based_level(n):
         np.testing.assert_allclose(proximal.device_prox(fa.L1Ball(t), x, 1.0), fo.project_l1(x, t), rtol=1e-12, atol=atol)
 
 
+@pytest.mark.parametrize("n", [700, 6000, 16384, 16385, 40000, 65536, 100000, 262144])
+def test_level_search_warm_started_from_any_previous_level(n):
+    """round 5: the search starts from the level the previous launch left behind (one workgroup up to n = 16384, several beyond).  Whatever
+    that guess is -- far below the new root, far above it, above EVERY entry, left over from a vector with ||x||_1 <= t -- the level
+    must equal the sort-based one of the reference (fasta/proximal.py:22-26) and be the same as from a cold start."""
+    rng = np.random.RandomState(n)
+    base = rng.randn(n) * rng.choice([0.01, 1.0, 30.0], size=n)
+    l1 = np.abs(base).sum()
+    # (scale of the vector, radius): consecutive launches on ONE cached context, so each search is warm-started from the one before
+    sequence = [(1.0, 0.5 * l1), (1.02, 0.5 * l1), (0.97, 0.52 * l1), (1e-3, 1e-4 * l1), (1.0, 1e-3), (50.0, 0.9 * 50 * l1), (1.0, 3.0 * l1), (1.0, 0.2 * l1),
+                (1e-6, 1e-9 * l1)]
+    for scale, t in sequence:
+        x = base * scale
+        atol = 4e-16 * n * max(1.0, np.abs(x).max())
+        np.testing.assert_allclose(proximal.device_prox(fa.L1Ball(t), x, 1.0), fo.project_l1(x, t), rtol=1e-12, atol=atol)
+    cold = {}
+    for scale, t in sequence[:3]:                       # the same launches from a cold start (a fresh context each): bit-identical
+        proximal.release_scratch()
+        cold[(scale, t)] = proximal.device_prox(fa.L1Ball(t), base * scale, 1.0)
+    proximal.release_scratch()
+    for scale, t in sequence[:3]:
+        assert np.array_equal(proximal.device_prox(fa.L1Ball(t), base * scale, 1.0), cold[(scale, t)])
+
+
 TV_SHAPES = [(1, 1), (1, 5), (5, 1), (2, 2), (16, 128), (17, 129), (33, 300), (40, 257), (96, 96)]
 
 

@@ -1,0 +1,161 @@
+"""fh_setup: the solver's whole set-up -- the two Lipschitz probes (fasta/__init__.py:100-113) and the initial pass (:135-137) -- from ONE
+read of a dense A (csrc/fh_setup.h: two dot products and two rank-1 updates per row buffer: x0, and the probes' difference, because
+grad(x1) - grad(x2) = A^T A (x1 - x2) for least squares), against the three separate passes fh_gradient_at x 2 + fh_init it replaces.
+The x0 column is summed in the order the one-pass kernel sums it, so z, f and g0 must come out BIT-identical; the norm of the
+gradient difference is formed another way (no cancellation between independent probes: rtol 1e-12)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from fasta_python_amd import hip
+from oracle import fasta_np as fo
+from oracle import problems as pr
+
+pytestmark = pytest.mark.gpu
+
+
+def _three_pass(c, n, m):
+    c.timing_reset(); c.timing_enable(True)
+    c.gradient_at(hip.VEC_T0, hip.VEC_T2)
+    c.gradient_at(hip.VEC_T1, hip.VEC_T3)
+    dg, dx = c.diff_norm(hip.VEC_T2, hip.VEC_T3), c.diff_norm(hip.VEC_T0, hip.VEC_T1)
+    s = c.init()
+    c.timing_enable(False)
+    return dict(s=s, dg=dg, dx=dx, t2=c.get_vector(hip.VEC_T2, n), t3=c.get_vector(hip.VEC_T3, n), g0=c.get_vector(hip.VEC_G0, n),
+                z=c.get_vector(hip.VEC_Z, m), one_pass_launches=c.timing_get(hip.K_FUSED)[1])
+
+
+def _one_call(c, n, m):
+    c.timing_reset(); c.timing_enable(True)
+    s = c.setup()
+    c.timing_enable(False)
+    return dict(s=s, dg=np.sqrt(s[hip.S_DG2]), dx=np.sqrt(s[hip.S_DX2]), t2=c.get_vector(hip.VEC_T2, n), t3=c.get_vector(hip.VEC_T3, n),
+                g0=c.get_vector(hip.VEC_G0, n), z=c.get_vector(hip.VEC_Z, m), one_pass_launches=c.timing_get(hip.K_FUSED)[1])
+
+
+def _load(c, rng, m, n, loss):
+    p1, p2, x0 = rng.randn(n), rng.randn(n), rng.randn(n) * 0.05
+    if loss == "logistic":
+        c.set_loss_logistic(np.sign(rng.randn(m)))
+    else:
+        c.set_loss_lsq(rng.randn(m))
+    c.set_prox(hip.PROX_SHRINK, 0.02)
+    for which, v in ((hip.VEC_T0, p1), (hip.VEC_T1, p2), (hip.VEC_X0, x0)):
+        c.set_vector(which, v)
+    return p1, p2, x0
+
+
+# teams of 1, 2, 4, 8, 16 members (n <= 4096, 8192, 16384, 32768, 65536), full and ragged widths, few and many rows per team
+SHAPES = [(2100, 4096), (4200, 2000), (9000, 1000), (1100, 8192), (1500, 6000), (600, 16384), (700, 12000), (300, 32768), (330, 20000),
+          (150, 65536), (260, 50000), (37, 65536), (1, 40000)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_one_read_of_A_serves_the_two_probes_and_the_initial_pass(m, n, loss="lsq"):
+    rng = np.random.RandomState(m * 3 + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap(A)
+    try:
+        c = op.ctx
+        assert c.fused_supported() == 1
+        p1, p2, x0 = _load(c, rng, m, n, loss)
+        want = _three_pass(c, n, m)
+        for which, v in ((hip.VEC_T2, np.zeros(n)), (hip.VEC_T3, np.zeros(n))):          # nothing may survive from the first run
+            c.set_vector(which, v)
+        c.set_vector(hip.VEC_X0, x0)
+        got = _one_call(c, n, m)
+        assert want["one_pass_launches"] == 3 and got["one_pass_launches"] == 1           # three reads of A -> one
+        for key in ("g0", "z"):
+            assert np.array_equal(got[key], want[key]), key
+        for k in (hip.S_GSUM, hip.S_GMAX, hip.S_FSQ):
+            assert got["s"][k] == want["s"][k]
+        b = c.get_vector(hip.VEC_B, m)
+        np.testing.assert_allclose(got["s"][hip.S_FSQ], np.sum((A @ x0 - b) ** 2), rtol=1e-11)
+        np.testing.assert_allclose(got["t2"], A.T @ (A @ (p1 - p2)), rtol=1e-9, atol=1e-12 * np.abs(want["t2"]).max())     # A^T A (x1 - x2)
+        np.testing.assert_allclose([got["dg"], got["dx"]], [want["dg"], want["dx"]], rtol=1e-12)
+        np.testing.assert_allclose(got["dg"], np.linalg.norm(A.T @ (A @ p1 - b) - A.T @ (A @ p2 - b)), rtol=1e-11)         # the reference's expression (:106-110)
+        np.testing.assert_allclose(got["dx"], np.linalg.norm(p1 - p2), rtol=1e-12)
+        # and the state fh_init leaves: the first iteration after either set-up is the same launch
+        s1 = c.step(0.3)
+        c.set_vector(hip.VEC_X0, x0)
+        c.init()
+        assert np.array_equal(c.step(0.3), s1)
+    finally:
+        op.close()
+
+
+@pytest.mark.parametrize("m,n,storage,loss", [(40, 100000, "f64", "lsq"), (30, 200000, "f64", "lsq"), (300, 16384, "f32", "lsq"), (96, 160, "f64", "lsq"),
+                                               (64, 4096, "f64", "lsq"), (600, 16384, "f64", "logistic"), (2100, 4096, "f64", "logistic")])
+def test_shapes_without_a_one_read_kernel_take_the_three_passes_inside_the_call(m, n, storage, loss):
+    """rows wider than 65536 columns, float32 storage, the logistic loss (its gradient is not linear in x: no difference trick), matrices
+    too small for the one-pass kernel to pay: fh_setup is the three passes, with their results bit for bit."""
+    rng = np.random.RandomState(n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap(A, storage=storage)
+    try:
+        c = op.ctx
+        _load(c, rng, m, n, loss)
+        want = _three_pass(c, n, m)
+        got = _one_call(c, n, m)
+        assert got["one_pass_launches"] == want["one_pass_launches"]
+        for key in ("t2", "t3", "g0", "z"):
+            assert np.array_equal(got[key], want[key]), key
+        for k in (hip.S_FSQ, hip.S_GSUM, hip.S_GMAX):
+            assert got["s"][k] == want["s"][k]
+        np.testing.assert_allclose([got["dg"], got["dx"]], [want["dg"], want["dx"]], rtol=1e-14)
+    finally:
+        op.close()
+
+
+def test_a_timed_out_set_up_launch_falls_back_to_the_three_passes():
+    """fault injection (a withheld team partial): the launch ends with its timeout word set, fh_setup redoes the set-up pass by pass --
+    which time out as well and end in K-fwd / K-adj -- and still delivers the right vectors."""
+    import time
+    rng = np.random.RandomState(5)
+    m, n = 1100, 8192
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    op = fa.DenseMatrixMap(A)
+    try:
+        c = op.ctx
+        p1, p2, x0 = _load(c, rng, m, n, "lsq")
+        b = c.get_vector(hip.VEC_B, m)
+        c.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_WITHHOLD_PARTIAL)
+        t0 = time.time()
+        s = c.setup()
+        assert time.time() - t0 < 10.0
+        c.set_tuning(hip.TUNE_TEST_HOOKS, 0)
+        np.testing.assert_allclose(c.get_vector(hip.VEC_G0, n), A.T @ (A @ x0 - b), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(s[hip.S_DG2], np.sum((A.T @ (A @ (p1 - p2))) ** 2), rtol=1e-9)
+        got = c.step(0.3)                                                 # the hand-off slots are usable again
+        assert np.isfinite(got).all() and got[15] == 0.0
+    finally:
+        op.close()
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "accelerated"])
+def test_full_solve_through_the_one_read_set_up_matches_the_oracle(mode):
+    np.random.seed(2)
+    P = pr.sparse_least_squares(M=2100, N=4096, K=40)
+    opts = dict(tolerance=1e-6, max_iters=60, evaluate_objective=True, adaptive=(mode == "adaptive"), accelerate=(mode != "adaptive"))
+    np.random.seed(4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    ls, reg = fa.LeastSquares(P.data["b"]), fa.Shrink(P.data["mu"])
+    op = fa.DenseMatrixMap(P.data["A"])
+    try:
+        op.ctx.timing_enable(True)
+        np.random.seed(4)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, backend="hip", **opts)
+        launches = op.ctx.timing_get(hip.K_FUSED)[1]
+    finally:
+        op.close()
+    k = want.iteration_count
+    assert got.iteration_count == k and got.backtracks == want.backtracks
+    assert launches == 1 + k + got.backtracks                            # ONE launch for the whole set-up, one per iteration / retry
+    np.testing.assert_allclose(got.residuals[:k], want.residuals[:k], rtol=1e-6)
+    np.testing.assert_allclose(got.stepsizes[:k], want.stepsizes[:k], rtol=1e-8)
+    np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)

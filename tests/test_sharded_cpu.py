@@ -228,3 +228,15 @@ def test_a_rank_stuck_for_good_is_ended_by_the_job_timeout():
     assert res.returncode != 0 and "--job-timeout" in res.stderr
     assert time.time() - t0 < 60
     assert not [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_preflight_without_a_gpu_fails_at_its_first_step_with_one_line():
+    """fasta_python_amd/preflight.py on a GPU-less box: ONE line on stderr naming the step, exit status 3 -- never a traceback, and
+    never a fallback to something that "passes"."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "fasta_python_amd.preflight", "2", "--inproc"], capture_output=True, text=True, timeout=120, cwd=root)
+    lines = [ln for ln in res.stderr.splitlines() if ln.strip()]
+    assert res.returncode == 3, res.stderr[-2000:]
+    assert len(lines) == 1 and lines[0].startswith("fasta preflight FAILED at step 'device count'"), res.stderr[-2000:]
