@@ -181,8 +181,9 @@ static int launch_level_search(fh_ctx* c, double tau) {
     return 0;
   }
   t_begin(c, FH_K_LEVEL);
-  if (n <= 1u * LVL_WG) k_level_search<1><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
-  else if (n <= 4u * LVL_WG) k_level_search<4><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  if (n <= 4u * 256u) k_level_search<4, 256><<<dim3(1), dim3(256), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else if (n <= 16u * 256u) k_level_search<16, 256><<<dim3(1), dim3(256), 0, c->stream>>>(x0, g0, n, tau, radius, out);
+  else if (n <= 32u * 256u) k_level_search<32, 256><<<dim3(1), dim3(256), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 16u * LVL_WG) k_level_search<16><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else if (n <= 64u * LVL_WG) k_level_search<64><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);
   else k_level_search<0><<<dim3(1), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out);

@@ -13,6 +13,7 @@
 
 #define LVL_WG 1024
 
+template <int WG = LVL_WG>
 __device__ __forceinline__ void lvl_reduce2(double& s, double& c, double* sa, double* sb) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   s = wave_sum(s); c = wave_sum(c);
@@ -21,7 +22,7 @@ __device__ __forceinline__ void lvl_reduce2(double& s, double& c, double* sa, do
   __syncthreads();
   double ts = 0.0, tc = 0.0;
 #pragma unroll
-  for (int w = 0; w < LVL_WG / 64; ++w) { ts += sa[w]; tc += sb[w]; }   // same order in every thread
+  for (int w = 0; w < WG / 64; ++w) { ts += sa[w]; tc += sb[w]; }   // same order in every thread
   s = ts; c = tc;
 }
 
@@ -32,11 +33,14 @@ __device__ __forceinline__ void lvl_reduce2(double& s, double& c, double* sa, do
 // (profiles/r05_level_search.txt).  The result is the same as from a cold start: the iteration ends on the same final active set,
 // and the level is that set's (sum - t) / count, summed in the same fixed order.  A guess that is not a positive finite number, or
 // lies above every entry, is ignored (cold start).  x0 / g0 are read as 16-byte pairs.
-template <int EPT>
-__global__ __launch_bounds__(LVL_WG) void k_level_search(const double* x0, const double* g0, uint32_t n, double tau,
-                                                         double radius, double* level_out) {
-  __shared__ __attribute__((aligned(16))) double sa[LVL_WG / 64];
-  __shared__ __attribute__((aligned(16))) double sb[LVL_WG / 64];
+// WG threads: 1024, or 256 for n <= 8192 (four waves: a pass is one short scan and a four-term sum -- a quarter of the barrier and
+// reduction work of sixteen waves, which is what a pass costs at these sizes).
+template <int EPT, int WG = LVL_WG>
+__global__ __launch_bounds__(WG) void k_level_search(const double* x0, const double* g0, uint32_t n, double tau,
+                                                     double radius, double* level_out) {
+  constexpr uint32_t LVL_WG_ = WG;
+  __shared__ __attribute__((aligned(16))) double sa[WG / 64];
+  __shared__ __attribute__((aligned(16))) double sb[WG / 64];
   const uint32_t tid = threadIdx.x;
   constexpr int PAIRS = EPT >= 2 ? EPT / 2 : 0;           // EPT = 1: one element per thread; EPT = 0: re-read every pass (n > 65536)
   double ax[EPT > 0 ? EPT : 1];
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(LVL_WG) void k_level_search(const double* x0, const
   if (PAIRS > 0) {
 #pragma unroll
     for (int k = 0; k < PAIRS; ++k) {
-      const uint32_t i = 2u * (tid + (uint32_t)k * LVL_WG);           // (n-side vectors are padded to a multiple of 16 doubles: in bounds)
+      const uint32_t i = 2u * (tid + (uint32_t)k * LVL_WG_);           // (n-side vectors are padded to a multiple of 16 doubles: in bounds)
       d2 xv = {0.0, 0.0}, gv = {0.0, 0.0};
       if (i < n) { xv = reinterpret_cast<const d2*>(x0)[i / 2]; gv = reinterpret_cast<const d2*>(g0)[i / 2]; }
       ax[2 * k] = i < n ? fabs(fwd_point(xv.x, gv.x, tau)) : -INFINITY;
@@ -61,14 +65,14 @@ __global__ __launch_bounds__(LVL_WG) void k_level_search(const double* x0, const
 #pragma unroll
       for (int k = 0; k < EPT; ++k) if (ax[k] > alpha) { s += ax[k]; cnt += 1.0; }
     } else {
-      for (uint32_t i = 2u * tid; i < n; i += 2u * LVL_WG) {
+      for (uint32_t i = 2u * tid; i < n; i += 2u * LVL_WG_) {
         const d2 xv = reinterpret_cast<const d2*>(x0)[i / 2], gv = reinterpret_cast<const d2*>(g0)[i / 2];
         const double a0 = fabs(fwd_point(xv.x, gv.x, tau)), a1 = fabs(fwd_point(xv.y, gv.y, tau));
         if (a0 > alpha) { s += a0; cnt += 1.0; }
         if (i + 1u < n && a1 > alpha) { s += a1; cnt += 1.0; }
       }
     }
-    lvl_reduce2(s, cnt, sa, sb);          // every thread now holds the same totals -> uniform control flow
+    lvl_reduce2<WG>(s, cnt, sa, sb);          // every thread now holds the same totals -> uniform control flow
     if (warm) {                           // the pass from the guess: its update is a lower bound of the root, whatever the guess was
       warm = false;
       if (cnt == 0.0) { alpha = -INFINITY; continue; }      // the guess lies above every entry: cold start
