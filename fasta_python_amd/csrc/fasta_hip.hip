@@ -20,6 +20,7 @@
 #include "fh_prox.h"
 #include "fh_fused.h"
 #include "fh_setup.h"
+#include "fh_run.h"
 
 // The one-pass kernel's variants: ONE table, fh_fused_instances.inc, drives (a) the explicit instantiations, compiled in four
 // parallel groups by fh_fused_part.hip, (b) their `extern template` declarations here and (c) the host dispatch table kFusedTable
@@ -209,6 +210,8 @@ extern "C" int fh_destroy(fh_ctx* c) {
   c->owner = nullptr;
   (void)fh_comm_destroy(c);
   free_operator(c);
+  if (c->run_st_host) (void)hipHostFree(c->run_st_host);
+  if (c->run_hist) (void)hipHostFree(c->run_hist);
   if (c->lvl_rec) (void)hipFree(c->lvl_rec);
   if (c->lvl_cnt) (void)hipFree(c->lvl_cnt);
   if (c->counters) (void)hipFree(c->counters);
@@ -956,6 +959,103 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
     return 0;
   }
   return dense_step(c, tau, 1, coef, restart, scalars);
+}
+
+// ---- the loop on the device (csrc/fh_run.h) --------------------------------------------------------------------------------------------
+struct RunEntry { int ppt; void (*kernel)(const RunP); };
+static const RunEntry kRunTable[] = {{1, k_run_dense<1>}, {2, k_run_dense<2>}, {4, k_run_dense<4>}, {5, k_run_dense<5>},
+                                     {6, k_run_dense<6>}, {7, k_run_dense<7>}, {8, k_run_dense<8>}};
+static const RunEntry* run_entry(fh_ctx* c) {
+  if (c->op != OP_DENSE || c->f32 || row_sharded(c) || !c->shards.empty()) return nullptr;
+  if (c->prox_kind != FH_PROX_IDENTITY && c->prox_kind != FH_PROX_SHRINK && c->prox_kind != FH_PROX_NONNEG && c->prox_kind != FH_PROX_BOX) return nullptr;
+  const FusedShape sh = fused_shape(c);
+  if (sh.team != 1 || sh.xlds) return nullptr;
+  for (const RunEntry& e : kRunTable) if (e.ppt == sh.ppt) return &e;
+  return nullptr;
+}
+extern "C" int fh_run_supported(fh_ctx* c, int* yes) {
+  if (!c || !yes) return fail(FH_E_ARG, "null argument");
+  *yes = (run_entry(c) && co_resident(c)) ? 1 : 0;
+  return 0;
+}
+extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_state* state, double* history, int* steps_done) {
+  FH_TRY(check_ready(c, true));
+  if (!o || !state || !history || !steps_done) return fail(FH_E_ARG, "fh_run: null argument");
+  if (max_steps < 0 || max_steps > 65536) return fail(FH_E_ARG, "fh_run: max_steps must be in [0, 65536]");
+  if (o->window < 1 || o->window > FH_RUN_WINDOW_MAX) return fail(FH_E_ARG, "fh_run: window must be in [1, %d]", FH_RUN_WINDOW_MAX);
+  if (o->stop_rule < 0 || o->stop_rule > 3) return fail(FH_E_ARG, "fh_run: stop_rule must be 0..3 (the four rules of fasta/stopping.py)");
+  const RunEntry* e = run_entry(c);
+  if (!e || !co_resident(c)) return fail(FH_E_STATE, "fh_run: no device-side loop for this operator / loss / prox (see fh_run_supported)");
+  FH_TRY(use_device(c));
+  FH_TRY(not_lazy(c, "fh_run"));
+  if (!c->run_st_host) {
+    HIP_TRY(hipHostMalloc(&c->run_st_host, sizeof(RunState), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(&c->run_st_host_dev, c->run_st_host, 0));
+  }
+  if ((size_t)max_steps > c->run_hist_steps) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->run_hist) { HIP_TRY(hipHostFree(c->run_hist)); c->run_hist = nullptr; c->run_hist_steps = 0; }
+    const size_t steps = round_up((size_t)max_steps, 256);
+    HIP_TRY(hipHostMalloc((void**)&c->run_hist, steps * FR_HIST * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->run_hist_dev, c->run_hist, 0));
+    c->run_hist_steps = steps;
+  }
+  RunP p;
+  RunState* hs = &p.init;                               // the state on entry travels as a kernel argument
+  memset(hs, 0, sizeof(RunState));
+  hs->tau_next = state->tau_next; hs->alpha1 = state->alpha1; hs->max_residual = state->max_residual; hs->best_quality = state->best_quality;
+  hs->iteration = state->iteration; hs->backtracks = state->backtracks; hs->stopped = 0;
+  hs->xi = c->xi; hs->ti = c->ti; hs->bi = c->bi; hs->pc = c->pc; hs->gc = c->gc; hs->zc = c->zc; hs->last_accel = c->last_accel ? 1 : 0;
+  for (int q = 0; q < 5; ++q) hs->perm[q] = q;
+  memcpy(hs->f_window, state->f_window, sizeof(hs->f_window));
+  p.A = c->A; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
+  p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.ldp = (uint32_t)(c->ld / 2); p.nv2 = p.ld2;
+  p.nteams = (uint32_t)fused_ncu(c);
+  if (c->fused_min_rows > 0) {
+    const uint64_t want = std::max<uint64_t>(8, round_up((c->mp + c->fused_min_rows - 1) / c->fused_min_rows, 8));
+    p.nteams = (uint32_t)std::min<uint64_t>(p.nteams, want);
+  }
+  p.rows_per_team = (uint32_t)((c->mp + p.nteams - 1) / p.nteams);
+  double* nb[5] = {c->X[0], c->X[1], c->X[2], c->P[0], c->P[1]};
+  for (int q = 0; q < 5; ++q) p.nbuf[q] = nb[q];
+  p.G[0] = c->G[0]; p.G[1] = c->G[1]; p.Z[0] = c->Z[0]; p.Z[1] = c->Z[1]; p.xhat = c->xhat; p.b = c->b;
+  p.loss = c->loss_kind; p.prox_kind = c->prox_kind; p.mu = c->mu; p.lo = c->lo; p.hi = c->hi;
+  p.nt = c->nt_loads;
+  p.g_kind = c->prox_kind == FH_PROX_SHRINK ? 1 : 0;
+  p.o.adaptive = o->adaptive; p.o.accelerate = o->accelerate; p.o.backtrack = o->backtrack; p.o.restart = o->restart;
+  p.o.evaluate_objective = o->evaluate_objective; p.o.stop_rule = o->stop_rule; p.o.window = o->window; p.o.max_backtracks = o->max_backtracks;
+  p.o.stepsize_shrink = o->stepsize_shrink; p.o.tolerance = o->tolerance;
+  p.max_steps = max_steps;
+  p.st_out = (RunState*)c->run_st_host_dev; p.hist = c->run_hist_dev;
+  memset(c->run_st_host, 0xFF, sizeof(RunState));     // (poisoned: a launch that never wrote its state back cannot pass for one that did)
+  const unsigned grid = p.nteams;
+  const size_t gpart_elems = (size_t)grid * p.nv2 * 2;
+  FH_TRY(ensure_ws(c, (gpart_elems + (size_t)2 * grid * 16) * sizeof(double)));
+  p.gpart = c->ws; p.red = p.gpart + gpart_elems;
+  HIP_TRY(hipMemsetAsync(c->counters + CNT_RUN_BAR, 0, 2 * sizeof(unsigned), c->stream));
+  p.bar = c->counters + CNT_RUN_BAR; p.err = c->counters + CNT_RUN_BAR + 1;
+  t_begin(c, FH_K_FUSED);
+  e->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  t_end(c, FH_K_FUSED);
+  HIP_TRY(hipGetLastError());
+  FH_TRY(finish(c));
+  hs = (RunState*)c->run_st_host;                       // the state on exit, written by the launch
+  if (hs->stopped == 3)
+    return fail(FH_E_STATE, "fh_run: a grid barrier of the persistent launch timed out (workgroups not co-resident?) -- the solver state is undefined; call fh_init");
+  // adopt the state the launch left: buffer roles and indices exactly as fh_commit would have left them
+  double* nx[5];
+  for (int q = 0; q < 5; ++q) nx[q] = nb[hs->perm[q]];
+  c->X[0] = nx[0]; c->X[1] = nx[1]; c->X[2] = nx[2]; c->P[0] = nx[3]; c->P[1] = nx[4];
+  c->xi = hs->xi; c->ti = hs->ti; c->bi = hs->bi; c->pc = hs->pc; c->gc = hs->gc; c->zc = hs->zc; c->last_accel = hs->last_accel != 0;
+  const int done = (int)(hs->iteration - state->iteration);
+  c->commits += (uint64_t)done;
+  c->slots_sig = 0;
+  state->tau_next = hs->tau_next; state->alpha1 = hs->alpha1; state->max_residual = hs->max_residual; state->best_quality = hs->best_quality;
+  state->iteration = hs->iteration; state->backtracks = hs->backtracks; state->stopped = hs->stopped;
+  memcpy(state->f_window, hs->f_window, sizeof(hs->f_window));
+  memcpy(history, c->run_hist, (size_t)done * FR_HIST * sizeof(double));
+  *steps_done = done;
+  return 0;
 }
 
 extern "C" int fh_commit(fh_ctx* c, int save_best) {

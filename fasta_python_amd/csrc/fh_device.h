@@ -216,6 +216,15 @@ __device__ __forceinline__ void store_partial2(d2* p, d2 v) {
   store_partial(reinterpret_cast<double*>(p), v.x);
   store_partial(reinterpret_cast<double*>(p) + 1, v.y);
 }
+// The same hand-off store as ONE 16-byte write-through instruction (`global_store_dwordx4 ... sc1`), for bulk partials (a slice of g1
+// per workgroup: tens of KiB).  As two 8-byte atomic stores each half is a fabric write of its own -- publishing a 32-KiB slice that way
+// took ~10 us of every launch (round 5: csrc/fh_run.h's phase table; CDNA4 guide, Guideline 16 pitfall 7).  An asm store is invisible to
+// hipcc's vmcnt bookkeeping; that is safe here because (a) uncounted operations only make its counted waits wait for MORE, and (b) every
+// consumer of these bytes sits behind arrive_last / a grid barrier, both of which drain vmcnt(0) explicitly.  (`s_nop 1`: the data registers
+// may not be overwritten before the store has read them.)
+__device__ __forceinline__ void store_partial16(d2* p, d2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ d2 load_partial2(const d2* p) {
   d2 v;
   v.x = load_partial(reinterpret_cast<const double*>(p));

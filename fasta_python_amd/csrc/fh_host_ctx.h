@@ -204,6 +204,9 @@ struct fh_ctx {
   std::vector<fh_ctx*> shards;       // non-empty: this context is a shell
   std::vector<uint64_t> shard_row0;  // first row of every shard, plus the total (size shards + 1)
   fh_ctx* owner = nullptr;           // set in a shard
+  // fh_run (csrc/fh_run.h): the host-mapped block the launch writes its final solver state to, and the host-mapped history block
+  void* run_st_host = nullptr; void* run_st_host_dev = nullptr;
+  double* run_hist = nullptr; double* run_hist_dev = nullptr; size_t run_hist_steps = 0;
   double* lvl_rec = nullptr;         // multi-workgroup level search: per-pass records and counters (allocated on first use, counters kept zero)
   unsigned* lvl_cnt = nullptr;
   double* selftest_buf = nullptr;    // fh_comm_selftest's scratch (freed before it returns)
@@ -219,7 +222,7 @@ static inline fh_ctx* shard_of(fh_ctx* c, int k) { return c->shards.empty() ? c 
 static inline bool row_sharded(const fh_ctx* c) { return c->comm != nullptr || c->owner != nullptr; }
 
 static const int kCounterWords = 8192;
-enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_PROBE = 12, CNT_ADJ_CC = 16 };
+enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_PROBE = 12, CNT_RUN_BAR = 14, CNT_ADJ_CC = 16 };
 
 static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 

@@ -39,6 +39,21 @@ _u64, _i32, _dbl = C.c_uint64, C.c_int, C.c_double
 _ctx = C.c_void_p
 _pd = C.POINTER(C.c_double)
 
+RUN_HIST, RUN_WINDOW_MAX = 8, 64
+STOP_RULES = ("residual", "norm_residual", "ratio_residual", "hybrid_residual")      # fh_run_opts.stop_rule = index (fasta/stopping.py:6-51)
+
+
+class RunOpts(C.Structure):                 # fh_run_opts
+    _fields_ = [(k, _i32) for k in ("adaptive", "accelerate", "backtrack", "restart", "evaluate_objective", "stop_rule", "window",
+                                    "max_backtracks")] + [("stepsize_shrink", _dbl), ("tolerance", _dbl)]
+
+
+class RunState(C.Structure):                # fh_run_state
+    _fields_ = [("tau_next", _dbl), ("alpha1", _dbl), ("max_residual", _dbl), ("best_quality", _dbl), ("iteration", _u64), ("backtracks", _u64),
+                ("stopped", _i32), ("reserved", _i32), ("f_window", _dbl * RUN_WINDOW_MAX)]
+
+
+
 # every exported symbol with its signature; tests assert the .so exports exactly these ------------
 SIGNATURES = {
     "fh_last_error": (C.c_char_p, []),
@@ -68,6 +83,8 @@ SIGNATURES = {
     "fh_fwd": (_i32, [_ctx, _dbl, _pd]),
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
+    "fh_run_supported": (_i32, [_ctx, C.POINTER(_i32)]),
+    "fh_run": (_i32, [_ctx, _i32, C.POINTER(RunOpts), C.POINTER(RunState), _pd, C.POINTER(_i32)]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_fused_agree": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_coresident_probe": (_i32, [_ctx, _i32, C.POINTER(_i32)]),
@@ -386,6 +403,20 @@ class HipContext:
         if self._scal[15] != 0.0:
             raise HipTimeout("fused one-pass kernel: team hand-off timed out (workgroups not co-resident?)")
         return self._scal.copy()
+
+    def run_supported(self):
+        """True if fh_run (the loop on the device, csrc/fh_run.h) has a kernel for this context's operator, loss and prox."""
+        yes = _i32(0)
+        self._call("fh_run_supported", C.byref(yes))
+        return bool(yes.value)
+
+    def run(self, max_steps, opts, state):
+        """Up to `max_steps` FBS iterations in one persistent launch.  `opts`: RunOpts, `state`: RunState (updated in place).
+        Returns the (steps, RUN_HIST) history block: residual, norm_residual, stepsize, f, objective, backtracks, alpha0, became-best."""
+        hist = np.empty((int(max_steps), RUN_HIST))
+        done = _i32(0)
+        self._call("fh_run", int(max_steps), C.byref(opts), C.byref(state), hist.ctypes.data_as(_pd), C.byref(done))
+        return hist[:done.value]
 
     def commit(self, save_best=False):
         self._call("fh_commit", 1 if save_best else 0)

@@ -110,12 +110,18 @@ class FBSolver:
     def __init__(self, A, loss, prox, x0, adaptive=True, accelerate=False, verbose=True, max_iters=1000,
                  tolerance=1e-5, stop_rule=stopping.hybrid_residual, L=None, tau0=None, backtrack=True,
                  stepsize_shrink=None, window=10, max_backtracks=20, restart=True, evaluate_objective=False,
-                 record_iterates=False, func=None, *, fused="auto"):
-        """Reference options (fasta/__init__.py:42-53) plus one build-only, keyword-only switch:
+                 record_iterates=False, func=None, *, fused="auto", device_iters=0):
+        """Reference options (fasta/__init__.py:42-53) plus two build-only, keyword-only switches:
         fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step` / `step_accel`, csrc/fh_fused.h)
         when the operator shape supports it (with acceleration: dense operator only).  It is speculative: the
         launch assumes the step is accepted; when the backtracking test fails the iteration falls back to
-        K-fwd/K-adj (same results)."""
+        K-fwd/K-adj (same results).
+        device_iters = K > 0 (opt-in) -- run the loop itself on the device, K iterations per persistent launch (`HipContext.run`,
+        csrc/fh_run.h): backtracking, FISTA, the Barzilai-Borwein rule and the stop rule are decided there, the histories come back
+        in one block.  For short iterations (n <= 4096), where launches and host round trips dominate.  Taken only when nothing
+        needs the host between two iterations -- `stop_rule` is one of the four of fasta/stopping.py, no `func`, no
+        `record_iterates`, `verbose` off -- and the context has a kernel for it; otherwise the per-iteration path runs (same
+        results, `device_steps` stays 0).  `times[i]` within one launch are interpolated between its start and its end."""
         self.A, self.loss, self.prox = A, loss, prox
         self.fused_opt = fused
         self.ctx = A.ctx
@@ -130,6 +136,8 @@ class FBSolver:
         self.backtrack, self.stepsize_shrink = backtrack, stepsize_shrink
         self.window, self.max_backtracks, self.restart = window, max_backtracks, restart
         self.evaluate_objective, self.record_iterates, self.func = evaluate_objective, record_iterates, func
+        self.device_iters = int(device_iters or 0)
+        self.device_steps = 0                  # iterations that ran inside persistent launches
 
     # ------------------------------------------------------------------------------------------
     def setup(self):
@@ -219,7 +227,48 @@ class FBSolver:
         self.tau_next = tau0
         self.i = 0
         self.done = False
+        self._run_opts = self._device_loop_options() if self.device_iters > 0 else None
         return self
+
+    # ------------------------------------------------------------------------------------------
+    def _device_loop_options(self):
+        """hip.RunOpts when the loop can run on the device (see __init__), else None."""
+        rules = {getattr(stopping, name): k for k, name in enumerate(hip.STOP_RULES)}
+        c = self.ctx
+        if (self.stop_rule not in rules or self.func or self.record_iterates or self.verbose or not hasattr(c, "run_supported")
+                or not 1 <= int(self.window) <= hip.RUN_WINDOW_MAX or self.fused_opt is False or not c.run_supported()):
+            return None
+        o = hip.RunOpts()
+        o.adaptive, o.accelerate, o.backtrack, o.restart = int(bool(self.adaptive)), int(bool(self.accelerate)), int(bool(self.backtrack)), int(bool(self.restart))
+        o.evaluate_objective, o.stop_rule, o.window, o.max_backtracks = int(bool(self.evaluate_objective)), rules[self.stop_rule], int(self.window), int(self.max_backtracks)
+        o.stepsize_shrink = float(self.stepsize_shrink) if self.backtrack else 1.0
+        o.tolerance = float(self.tolerance)
+        return o
+
+    def _run_on_device(self):
+        """The loop in persistent launches of `device_iters` iterations each (csrc/fh_run.h), until the stop rule fires or max_iters."""
+        c, st = self.ctx, hip.RunState()
+        while self.i < self.max_iters and not self.done:
+            i = self.i
+            st.tau_next, st.alpha1, st.max_residual, st.best_quality = self.tau_next, self.alpha1, self.max_residual, self.best_quality
+            st.iteration, st.backtracks, st.stopped = i, self.total_backtracks, 0
+            lo = max(i - self.window + 1, 0)
+            for j in range(lo, i + 1):
+                st.f_window[j % hip.RUN_WINDOW_MAX] = self.f_hist[j]
+            t0 = time()
+            h = c.run(min(self.device_iters, self.max_iters - i), self._run_opts, st)
+            t1 = time()
+            k = len(h)
+            self.residuals[i:i + k], self.norm_residuals[i:i + k], self.stepsizes[i:i + k] = h[:, 0], h[:, 1], h[:, 2]
+            self.f_hist[i + 1:i + k + 1] = h[:, 3]
+            if self.evaluate_objective:
+                self.objectives[i + 1:i + k + 1] = h[:, 4]
+            self.times[i:i + k] = t0 + (t1 - t0) * np.arange(k) / max(k, 1)         # (one launch: the iterations' stamps are interpolated)
+            self.tau_next, self.alpha1, self.max_residual, self.best_quality = st.tau_next, st.alpha1, st.max_residual, st.best_quality
+            self.total_backtracks = int(st.backtracks)
+            self.i = int(st.iteration)
+            self.device_steps += k
+            self.done = bool(st.stopped) or self.i >= self.max_iters
 
     def _forward(self, tau, one_pass):
         """(fwd scalars, adj scalars or None): the one-pass kernel when enabled and asked for, else K-fwd alone."""
@@ -347,7 +396,9 @@ class FBSolver:
             # the reference relies on float64 inf/nan semantics (e.g. 0/0 in the BB rule once converged)
             warnings.simplefilter("ignore", RuntimeWarning)
             with np.errstate(all="ignore"):
-                while self.i < self.max_iters:
+                if self._run_opts is not None:
+                    self._run_on_device()
+                while self.i < self.max_iters and not self.done:
                     if self.step():
                         break
         return self.result()
@@ -355,8 +406,10 @@ class FBSolver:
     def result(self):
         self.times[self.i] = time()                                     # :315
         solution = self.ctx.get_vector(hip.VEC_BEST, self.n).reshape(self.shape)
-        return Convergence(self.residuals, self.norm_residuals, self.stepsizes, self.total_backtracks, self.times,
+        conv = Convergence(self.residuals, self.norm_residuals, self.stepsizes, self.total_backtracks, self.times,
                            self.i, solution, self.objectives, self.iterates, self.function_hist)
+        conv.device_steps = self.device_steps         # (build-only diagnostic: iterations that ran inside persistent launches, `device_iters`)
+        return conv
 
 
 def fasta(A, *operands, backend="auto", **options):
@@ -365,7 +418,8 @@ def fasta(A, *operands, backend="auto", **options):
       backend = "auto"  -- device loop for device-recognisable operands (raises if the GPU path is unavailable), generic
                            host loop for operands that cannot run in a kernel (closures, callable pair, None, host LinearMap);
                 "hip"   -- device loop or TypeError;   "numpy" -- generic host loop (operands are called as given);
-      fused   = "auto" | True | False -- one-pass kernel policy of the device loop (see FBSolver)."""
+      fused   = "auto" | True | False -- one-pass kernel policy of the device loop (see FBSolver);
+      device_iters = K -- opt-in: the loop itself on the device, K iterations per persistent launch (see FBSolver)."""
     if len(operands) == 6:
         At, f, gradf, g, proxg, x0 = operands
     elif len(operands) == 5:
@@ -380,7 +434,8 @@ def fasta(A, *operands, backend="auto", **options):
         if backend == "hip":
             raise TypeError("fasta(backend='hip'): " + why_not)
         from .generic import HostFBS, host_map
-        options.pop("fused", None)                                      # device-loop policy, meaningless on the host
+        options.pop("fused", None)                                      # device-loop policies, meaningless on the host
+        options.pop("device_iters", None)
         x0 = np.asarray(x0)
         return HostFBS(host_map(A, At, x0), f, gradf, g, proxg, x0, **options).setup().run()
     x0 = np.asarray(x0, dtype=np.float64)

@@ -239,6 +239,35 @@ int fh_step_end(fh_ctx* ctx, double* scalars);
  * sweep; a solve that uses it must use it from the first iteration after fh_init (FH_E_STATE otherwise, and fh_fwd /
  * fh_adj / fh_step refuse until the next fh_init).  fh_get_vector(X0 | X1 | BEST) materialises the iterate.              */
 int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* scalars);
+/* ---- the loop itself on the device (opt-in: fasta(..., device_iters=K)) -----------------------------------------------------------
+ * fh_run executes up to max_steps FBS iterations -- fasta/__init__.py:171-312: forward step, prox, both matvecs, the non-monotone
+ * backtracking test with its retries (:195-217), FISTA restart and alpha recursion (:220-238), Barzilai-Borwein step (:253-270),
+ * residuals, best iterate (:272-300) and ONE OF THE FOUR BUILT-IN stop rules (fasta/stopping.py:6-51) -- in ONE persistent launch
+ * (csrc/fh_run.h), and returns the iterations' histories in one block.  For short launches, where the fixed cost of a launch and the
+ * host round trip between two launches dominate (n <= 4096: a workgroup owns whole rows).  Arithmetic and decisions are those of the
+ * per-iteration path (fh_step + the host driver), so iteration and backtrack counts are the same and histories agree to rounding.
+ *   opts    the options of fasta() the loop reads; stop_rule: 0 residual, 1 norm_residual, 2 ratio_residual, 3 hybrid_residual
+ *   state   in/out, carried from call to call: after fh_init / fh_setup set tau_next = tau0, alpha1 = 1, max_residual = -inf,
+ *           best_quality = +inf, iteration = backtracks = 0, f_window[0] = f(x0) (f_window[j % 64] holds f_hist[j]; window <= 64)
+ *   history max_steps records of FH_RUN_HIST doubles: residual, norm_residual, stepsize, f_hist[i+1], objective, backtracks of the
+ *           iteration, alpha0, 1 if the iterate became the best one
+ *   steps_done  iterations executed (fewer than max_steps when the stop rule fired: state->stopped = 1)
+ * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 4096 on a
+ * single-device context, a scalar-separable prox without level search, every CU free for one resident workgroup).                 */
+#define FH_RUN_HIST 8
+#define FH_RUN_WINDOW_MAX 64
+typedef struct fh_run_opts {
+  int adaptive, accelerate, backtrack, restart, evaluate_objective, stop_rule, window, max_backtracks;
+  double stepsize_shrink, tolerance;
+} fh_run_opts;
+typedef struct fh_run_state {
+  double tau_next, alpha1, max_residual, best_quality;
+  uint64_t iteration, backtracks;
+  int stopped, reserved;
+  double f_window[FH_RUN_WINDOW_MAX];
+} fh_run_state;
+int fh_run_supported(fh_ctx* ctx, int* yes);
+int fh_run(fh_ctx* ctx, int max_steps, const fh_run_opts* opts, fh_run_state* state, double* history, int* steps_done);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
  * copies x1 into FH_VEC_BEST (:298-300).                                                         */
 int fh_commit(fh_ctx* ctx, int save_best);

@@ -1,0 +1,152 @@
+"""fasta(..., device_iters=K): the FBS loop itself on the device (fh_run, csrc/fh_run.h) -- backtracking test and retries, FISTA restart
+and alpha recursion, Barzilai-Borwein step, residuals, best iterate and the four built-in stop rules decided inside ONE persistent
+launch per K iterations -- against the reference's recorded runs, the oracle, and the per-iteration path of the same library."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fasta_python_amd as fa
+from fasta_python_amd import hip, stopping
+from oracle import fasta_np as fo
+from oracle import problems as pr
+from tests import gpu_util as G
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DENSE = [n for n in H.golden_cases() if n.split("_")[0] in ("sparse", "nnls", "c1", "logistic")]
+PREFIX = {"sparse_ls_unnormalised_backtracks": 25, "nnls_under_first40": 25, "sparse_ls_opt_window3_shrink": 25}
+
+
+def _needs_the_host(options):
+    return bool(options.get("record_iterates") or options.get("func"))
+
+
+@pytest.mark.parametrize("K", [8, 1])
+@pytest.mark.parametrize("name", DENSE)
+def test_golden_parity_with_the_loop_on_the_device(name, K):
+    """Every dense fixture captured from the reference, run with device_iters=K: identical iteration and backtrack counts, histories
+    rtol 1e-6, solution rtol 1e-5 -- and the iterations really ran inside persistent launches (device_steps), except where an option
+    needs the host between iterations (record_iterates / func), which must fall back to the per-iteration path with the same result."""
+    meta, z = H.load_case(name)
+    data = H.case_data(meta, z)
+    opts = dict(meta["options"], device_iters=K)
+    k = PREFIX.get(name)
+    if k:
+        opts.update(max_iters=k, tolerance=0.0)
+    c = G.run_hip(meta["kind"], data, opts, meta["solver_seed"], g_none=meta["options"].get("g_none", False))
+    assert c.device_steps == (0 if _needs_the_host(meta["options"]) else c.iteration_count)
+    get = lambda f: z[f] if f in z.files else None
+    if k:
+        G.compare_histories(c, get, k, rtol=1e-6, atol=1e-14, fields=("residuals", "norm_residuals", "stepsizes"))
+        return
+    assert c.iteration_count == int(z["iteration_count"])
+    assert c.backtracks == int(z["backtracks"])
+    G.compare_histories(c, get, c.iteration_count, rtol=1e-6, atol=1e-14)
+    np.testing.assert_allclose(c.solution, z["solution"], rtol=1e-5, atol=1e-9)
+
+
+def _solve(A, b, reg, x0, **opts):
+    op = fa.DenseMatrixMap(A)
+    try:
+        ls = fa.LeastSquares(b)
+        np.random.seed(5)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g, prox = (None, None) if reg is None else (reg.g, reg.prox)
+            return fa.fasta(op, ls.f, ls.gradf, g, prox, x0, verbose=False, backend="hip", **opts)
+    finally:
+        op.close()
+
+
+MODES = {"adaptive": dict(), "accelerated": dict(adaptive=False, accelerate=True), "plain": dict(adaptive=False),
+         "accel_adaptive": dict(accelerate=True), "no_restart": dict(adaptive=False, accelerate=True, restart=False),
+         "forced_backtracking": dict(L=1.0, tau0=5000.0), "no_backtrack": dict(backtrack=False), "window3": dict(window=3, stepsize_shrink=0.4)}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("m,n", [(300, 4096), (96, 160), (700, 2000), (1500, 1000), (40, 3000)])
+def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    xt = np.zeros(n)
+    xt[rng.permutation(n)[:max(1, n // 50)]] = 1
+    b = A @ xt + 0.01 * rng.randn(m)
+    opts = dict(tolerance=1e-7, max_iters=120, evaluate_objective=True, **MODES[mode])
+    host = _solve(A, b, fa.Shrink(0.02), np.zeros(n), fused=True, **opts)
+    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=16, **opts)
+    assert host.device_steps == 0 and dev.device_steps == dev.iteration_count
+    k = host.iteration_count
+    assert dev.iteration_count == k and dev.backtracks == host.backtracks
+    if mode == "window3":       # a short window makes the run backtrack often and amplify rounding (the fixture of that name is pinned on a prefix too)
+        k = min(k, 30)
+    # (the per-iteration path takes K-fwd / K-adj for a few iterations after every backtrack: other summation orders, whose rounding the
+    # adaptive step sizes amplify over a solve -- the same tolerances as against the reference)
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(dev, f)[:k], getattr(host, f)[:k], rtol=2e-5, atol=1e-300, err_msg=f)
+    np.testing.assert_allclose(dev.objectives[:k + 1], host.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(dev.solution, host.solution, rtol=1e-5, atol=1e-9)
+    P = pr.sparse_least_squares_from(A, b, 0.02)
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    if mode == "forced_backtracking":
+        assert want.backtracks >= 4
+    assert dev.iteration_count == want.iteration_count and dev.backtracks == want.backtracks
+    np.testing.assert_allclose(dev.residuals[:k], want.residuals[:k], rtol=1e-6)
+    np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(dev.solution, want.solution, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("reg", ["nonneg", "box", "none"])
+def test_device_loop_with_the_other_separable_prox_kinds(reg):
+    rng = np.random.RandomState(12)
+    m, n = 400, 1200
+    A = rng.randn(m, n) / 40
+    b = rng.rand(m)
+    tag = {"nonneg": fa.NonNeg(), "box": fa.Box(-0.01, 0.02), "none": None}[reg]
+    opts = dict(tolerance=1e-6, max_iters=80, evaluate_objective=True)
+    host = _solve(A, b, tag, np.zeros(n), **opts)
+    dev = _solve(A, b, tag, np.zeros(n), device_iters=7, **opts)
+    k = host.iteration_count
+    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == host.backtracks
+    np.testing.assert_allclose(dev.residuals[:k], host.residuals[:k], rtol=2e-6)
+    np.testing.assert_allclose(dev.objectives[:k + 1], host.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(dev.solution, host.solution, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("rule", hip.STOP_RULES)
+def test_the_launch_length_does_not_change_a_single_bit(rule):
+    """K = 1, 3, 1000 iterations per launch: the state carried between launches (step size, alpha, f window, best iterate, maximal
+    residual, buffer roles) must make the solve independent of where the launches are cut."""
+    rng = np.random.RandomState(3)
+    m, n = 500, 2500
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = rng.randn(m)
+    runs = []
+    for K in (1, 3, 1000):
+        for acc in (False, True):
+            runs.append((acc, _solve(A, b, fa.Shrink(0.05), np.zeros(n), device_iters=K, tolerance=1e-4, max_iters=70, accelerate=acc,
+                                     adaptive=not acc, stop_rule=getattr(stopping, rule), evaluate_objective=acc)))
+    for acc in (False, True):
+        same = [r for a, r in runs if a == acc]
+        for r in same[1:]:
+            assert r.iteration_count == same[0].iteration_count and r.backtracks == same[0].backtracks and r.device_steps == r.iteration_count
+            for f in ("residuals", "norm_residuals", "stepsizes", "solution"):
+                assert np.array_equal(getattr(r, f), getattr(same[0], f)), f
+
+
+def test_options_that_need_the_host_between_iterations_keep_the_per_iteration_path():
+    rng = np.random.RandomState(4)
+    m, n = 200, 600
+    A = rng.randn(m, n) / 30
+    b = rng.randn(m)
+    for extra in (dict(func=lambda x: float(np.abs(x).sum())), dict(record_iterates=True), dict(stop_rule=lambda i, r, nr, mr, tol: i >= 9)):
+        got = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=8, max_iters=30, **extra)
+        ref = _solve(A, b, fa.Shrink(0.02), np.zeros(n), max_iters=30, **extra)
+        assert got.device_steps == 0 and got.iteration_count == ref.iteration_count
+        assert np.array_equal(got.residuals, ref.residuals) and np.array_equal(got.solution, ref.solution)
+    wide = _solve(rng.randn(50, 9000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(9000), device_iters=8, max_iters=10)     # n > 4096: no kernel
+    assert wide.device_steps == 0 and wide.iteration_count == 10
