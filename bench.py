@@ -587,6 +587,45 @@ def natural_runs(A, n, m_total):
     return out
 
 
+def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096)), iters=512, per_launch=64, repeats=3):
+    """fasta(..., device_iters=K) -- the FBS loop itself in persistent launches (fh_run, csrc/fh_run.h) -- against the per-iteration path on
+    the reference's own problem sizes (its examples are 200 x 1000 ... 1000 x 2000; SURVEY.md 8(d) config 1 is 512 x 1024), where a launch and
+    the host round trip cost more than the iteration's arithmetic.  Same synthetic LASSO recipe as the headline; best of `repeats` solves."""
+    import numpy as np
+    import fasta_python_amd as fa
+    from fasta_python_amd import synthetic
+    out = {}
+    for m, n in sizes:
+        A = fa.DenseMatrixMap.synthetic(m, n, seed=0, scale=synthetic.lasso_scale(m, n), device=grp.local_rank)
+        try:
+            x_true = synthetic.sparse_signal(n, seed=1)
+            b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=0.01)
+            loss, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+            rates = {}
+            for name, kw in (("per_iteration_launches", {}), ("device_loop", {"device_iters": per_launch})):
+                best, steps_on_device = 0.0, 0
+                for _ in range(repeats):
+                    np.random.seed(3)
+                    solver = fa.FBSolver(A, loss, reg, np.zeros(n), verbose=False, max_iters=iters, tolerance=0.0, **kw)
+                    with warnings.catch_warnings(), np.errstate(all="ignore"):
+                        warnings.simplefilter("ignore")
+                        solver.setup()
+                        A.ctx.sync()
+                        t0 = time.perf_counter()
+                        solver.run()
+                        A.ctx.sync()
+                        best = max(best, solver.i / (time.perf_counter() - t0))
+                    steps_on_device = solver.device_steps
+                rates[name] = {"iterations/s": best, "us_per_iteration": 1e6 / best, "iterations_inside_persistent_launches": steps_on_device}
+            rates["speedup"] = rates["device_loop"]["iterations/s"] / rates["per_iteration_launches"]["iterations/s"]
+            out[f"{m}x{n}"] = rates
+        finally:
+            A.close()
+    out["note"] = (f"{iters} iterations, tolerance 0, adaptive FBS with backtracking; device_loop = fasta(..., device_iters={per_launch}): backtracking test, "
+                   "Barzilai-Borwein step, residuals, best iterate and the stop rule are decided on the device, histories come back once per launch; opt-in")
+    return out
+
+
 def sub_result(r, workload):
     d = r["per_kernel"].get(r["dominant"], {}) if r["dominant"] else {}
     return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
@@ -884,6 +923,8 @@ def main(argv=None):
                 s["vs_materialised_model"] = r["vs_materialised_model"]
                 extra[key] = s
             extra["natural_run"] = natural_runs(A, n, m_total)
+            if "device_loop" not in args.skip_extra.split(","):
+                extra["device_loop"] = device_loop_runs(grp)
             # the single-call multi-device form (ShardedDenseMatrixMap, fh_create_ex ndev > 1) on this one GPU: the same matrix as 8
             # row blocks of 8192 x 65536, all on this device -- what the row-sharded plumbing (8 local launches, the sum over the
             # blocks, 8 n-side epilogues, one synchronisation) costs next to the single launch of the headline

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     const uint32_t c = cc * (FH_WG * CPT) + j * FH_WG + tid;
     if (c < p.ld2) {
 #pragma unroll
-      for (int e = 0; e < XD; ++e) store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)slab * p.nv2 + c * XD + e, acc[j][e]);
+      for (int e = 0; e < XD; ++e) store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)slab * p.nv2, c * XD + e, acc[j][e]);
     }
   }
   if (cc == 0) {

@@ -216,14 +216,23 @@ __device__ __forceinline__ void store_partial2(d2* p, d2 v) {
   store_partial(reinterpret_cast<double*>(p), v.x);
   store_partial(reinterpret_cast<double*>(p) + 1, v.y);
 }
-// The same hand-off store as ONE 16-byte write-through instruction (`global_store_dwordx4 ... sc1`), for bulk partials (a slice of g1
-// per workgroup: tens of KiB).  As two 8-byte atomic stores each half is a fabric write of its own -- publishing a 32-KiB slice that way
-// took ~10 us of every launch (round 5: csrc/fh_run.h's phase table; CDNA4 guide, Guideline 16 pitfall 7).  An asm store is invisible to
-// hipcc's vmcnt bookkeeping; that is safe here because (a) uncounted operations only make its counted waits wait for MORE, and (b) every
-// consumer of these bytes sits behind arrive_last / a grid barrier, both of which drain vmcnt(0) explicitly.  (`s_nop 1`: the data registers
-// may not be overwritten before the store has read them.)
-__device__ __forceinline__ void store_partial16(d2* p, d2 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+// The same hand-off store as ONE 16-byte write-through instruction (`buffer_store_dwordx4 ... offen sc1`), for bulk partials (a slice of
+// g1 per workgroup: tens of KiB).  As two 8-byte atomic stores each half is a fabric write of its own -- publishing a 32-KiB slice that
+// way took ~10 us of every launch (round 5: csrc/fh_run.h's phase table; CDNA4 guide, Guideline 16 pitfall 7).  Through the raw-buffer
+// builtin (aux 16 = sc1) hipcc counts the store in its vmcnt bookkeeping and may take the data straight from accumulator registers (an
+// asm store with "v" operands forced the slices into VGPRs and cost the 16-piece shape 13 %).  `base` must be wave-uniform (it becomes
+// the buffer descriptor: readfirstlane spares hipcc a waterfall loop), `idx` is this lane's double-pair index from it (< 2^27).
+typedef unsigned fh_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_partial16(d2* base, uint32_t idx, d2 v) {
+#ifdef FH_NARROW_PARTIALS      // A/B builds only: the two 8-byte atomic stores of rounds 1-4
+  store_partial2(base + idx, v);
+  return;
+#endif
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xFFFFFFFFu));
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)u, (short)0, 0x7FFFFFFF, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fh_u4, v), rs, idx * 16u, 0, 16);
 }
 __device__ __forceinline__ d2 load_partial2(const d2* p) {
   d2 v;

@@ -221,8 +221,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
       }
       if (XLDS) s_x[(k * XD + h) * FH_WG + tid] = xp; else xq[XLDS ? 0 : k][h] = xp;      // (each lane only ever reads back its own entries)
       if (team == 0 && c < p.ld2) {   // write-through: other workgroups read these back after the grid barrier
-        store_partial16(reinterpret_cast<d2*>(p.xhat) + cr, xh);
-        store_partial16(reinterpret_cast<d2*>(p.xp) + cr, xp);
+        store_partial16(reinterpret_cast<d2*>(p.xhat), cr, xh);
+        store_partial16(reinterpret_cast<d2*>(p.xp), cr, xp);
       }
     }
   }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     if (c0 + k * FH_WG < p.ld2) {
 #pragma unroll
       for (int h = 0; h < XD; ++h)
-        store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2 + (c0 + k * FH_WG) * XD + h, ga[k][h]);
+        store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2, (c0 + k * FH_WG) * XD + h, ga[k][h]);
     }
   {
     double w[8] = {fs, v[0], v[1], v[2], v[3], v[4], v[5], fsa};

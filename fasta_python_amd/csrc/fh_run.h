@@ -20,6 +20,9 @@
 // Vectors that one workgroup writes and another reads in the NEXT attempt (g1, x1, xprox, xhat) are stored write-through (sc1) and
 // loaded past L1 (sc1), as the CDNA4 guide's Guideline 16 prescribes for in-launch hand-offs; barriers are generation counters with
 // bounded spins (a timeout ends the launch with `stopped = 3`).
+// Measured and NOT shipped (round 5): rows of 4096 < n <= 8192 columns with 512-thread workgroups (two waves per SIMD, whole rows per
+// workgroup, x0 / g0 in LDS): correct, but hipcc spills ~210 registers per lane at two waves per SIMD and an iteration at 8192^2 takes
+// 209 us against 136 us on the per-iteration path (profiles/r05_device_loop.txt).  n <= 4096 it is.
 // Not here (the caller keeps the per-iteration path): Python hooks (stop_rule other than the four, func, record_iterates, verbose),
 // the level-search prox kinds, float32 storage, row sharding, wider rows.
 #pragma once
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       s_x[k * FH_WG + tid] = xp;
       if constexpr (!XLDS) xq[XLDS ? 0 : k] = xp;
       if (team == 0 && c < p.ld2) {
-        store_partial16(reinterpret_cast<d2*>(p.xhat) + c, xh);
-        store_partial16(reinterpret_cast<d2*>(xp_out) + c, xp);
+        store_partial16(reinterpret_cast<d2*>(p.xhat), c, xh);
+        store_partial16(reinterpret_cast<d2*>(xp_out), c, xp);
       }
     }
     block_reduce<7>(v, s_scr, 5);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
-      if (c0 + k * FH_WG < p.ld2) store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2 + (c0 + k * FH_WG), ga[k]);
+      if (c0 + k * FH_WG < p.ld2) store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2, c0 + k * FH_WG, ga[k]);
     if (tid == 0) { store_partial(red + (uint64_t)team * 16, fs); store_partial(red + (uint64_t)team * 16 + 7, fsa); }
     FR_STAMP(1);
     if (!fr_grid_barrier(p.bar, ++nbar * G, p.err, s_flag)) { stopped = 3; break; }
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
         }
       }
       if (!mine || slice != 0) continue;
-      store_partial16(reinterpret_cast<d2*>(g1) + c, g);
+      store_partial16(reinterpret_cast<d2*>(g1), c, g);
       const d2 x0v = load_partial2(reinterpret_cast<const d2*>(x0) + c);
       const d2 xpv = load_partial2(reinterpret_cast<const d2*>(xp_out) + c);
       const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       d2 x1v;
       x1v.x = bb_element(e, g.x, x0v.x, xpv.x, xav.x, xhv.x, 2u * c < p.n, u);
       x1v.y = bb_element(e, g.y, x0v.y, xpv.y, xav.y, xhv.y, 2u * c + 1u < p.n, u);
-      if (o.accelerate) store_partial16(reinterpret_cast<d2*>(x1_out) + c, x1v);
+      if (o.accelerate) store_partial16(reinterpret_cast<d2*>(x1_out), c, x1v);
     }
     block_reduce<5>(u, s_scr, 4);
     if (tid == 0) {

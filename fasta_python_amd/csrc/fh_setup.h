@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
       if (piece_ok(k))
-        store_partial16(reinterpret_cast<d2*>(p.gpart) + ((uint64_t)team * NR + j) * p.nv2 + (c0 + k * NT), ga[j][k]);
+        store_partial16(reinterpret_cast<d2*>(p.gpart) + ((uint64_t)team * NR + j) * p.nv2, c0 + k * NT, ga[j][k]);
   {
     double w[2] = {fs, dx2};
     fs_block_reduce<2, NW>(w, s_scr);

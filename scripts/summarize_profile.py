@@ -37,7 +37,7 @@ write = mean_counter("write", "WRITE_SIZE")
 out = {"units": "bytes per launch", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
        "read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
-    if not any(s in k for s in ("k_fwd", "k_adj", "k_fused", "k_stream", "k_tv", "k_gen")):
+    if not any(s in k for s in ("k_fwd", "k_adj", "k_fused", "k_stream", "k_tv", "k_gen", "k_setup", "k_run", "k_level")):
         continue
     rd = 2 * fetch.get(k, (0, 0))[0] * 1024
     wr = write.get(k, (0, 0))[0] * 1024

@@ -79,12 +79,12 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     assert host.device_steps == 0 and dev.device_steps == dev.iteration_count
     k = host.iteration_count
     assert dev.iteration_count == k and dev.backtracks == host.backtracks
-    if mode == "window3":       # a short window makes the run backtrack often and amplify rounding (the fixture of that name is pinned on a prefix too)
-        k = min(k, 30)
-    # (the per-iteration path takes K-fwd / K-adj for a few iterations after every backtrack: other summation orders, whose rounding the
-    # adaptive step sizes amplify over a solve -- the same tolerances as against the reference)
+    # Histories are pinned over the first 40 iterations: late in a solve the residuals are ~1e-8 of their start and the adaptive step sizes
+    # amplify summation-order rounding (the per-iteration path itself takes K-fwd / K-adj for a few iterations after every backtrack, i.e.
+    # other summation orders than the one-pass arithmetic of the device loop); counts and the solution are compared for the whole solve.
+    kk = min(k, 40)
     for f in ("residuals", "norm_residuals", "stepsizes"):
-        np.testing.assert_allclose(getattr(dev, f)[:k], getattr(host, f)[:k], rtol=2e-5, atol=1e-300, err_msg=f)
+        np.testing.assert_allclose(getattr(dev, f)[:kk], getattr(host, f)[:kk], rtol=1e-6, atol=1e-300, err_msg=f)
     np.testing.assert_allclose(dev.objectives[:k + 1], host.objectives[:k + 1], rtol=1e-8)
     np.testing.assert_allclose(dev.solution, host.solution, rtol=1e-5, atol=1e-9)
     P = pr.sparse_least_squares_from(A, b, 0.02)
@@ -95,7 +95,8 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     if mode == "forced_backtracking":
         assert want.backtracks >= 4
     assert dev.iteration_count == want.iteration_count and dev.backtracks == want.backtracks
-    np.testing.assert_allclose(dev.residuals[:k], want.residuals[:k], rtol=1e-6)
+    np.testing.assert_allclose(dev.residuals[:kk], want.residuals[:kk], rtol=1e-6)
+    np.testing.assert_allclose(dev.stepsizes[:kk], want.stepsizes[:kk], rtol=1e-6)
     np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
     np.testing.assert_allclose(dev.solution, want.solution, rtol=1e-5, atol=1e-9)
 

@@ -41,7 +41,10 @@ def test_oracle_against_itself_with_a_permuted_summation_order(H, W, seed):
     # the transposed operators ARE the originals, bit for bit, through the map
     Yr = np.random.RandomState(1).randn(H, W, 2)
     assert np.array_equal(A2(np.ascontiguousarray(T(Yr))).T, P.A(Yr)) and np.array_equal(proxg2(np.ascontiguousarray(T(Yr)), 1.0), np.ascontiguousarray(T(P.proxg(Yr, 1.0))))
-    with warnings.catch_warnings():
+    # (one BLAS thread: the loop makes ~10^5 norm / dot calls on 40-KiB arrays; OpenBLAS's worker threads spin between calls, and under a
+    # CPU quota that turned these two solves from seconds into minutes)
+    from threadpoolctl import threadpool_limits
+    with warnings.catch_warnings(), threadpool_limits(limits=1, user_api="blas"):
         warnings.simplefilter("ignore")
         a = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, P.x0, **opts)
         b = fo.fasta(A2, At2, f2, gradf2, g2, proxg2, Y02, **opts)
