@@ -300,10 +300,9 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     const uint32_t piece = cc * (FH_WG * CPT) + (j / XD) * FH_WG + tid;
     if (piece >= p.ld2) continue;
     const uint32_t c = piece * XD + (j % XD);                      // double-pair index into the n-side vectors
-    const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
     d2 g = {0.0, 0.0};
 #pragma unroll 16
-    for (uint32_t s = 0; s < p.nslab; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
+    for (uint32_t s = 0; s < p.nslab; ++s) g += load_partial16(reinterpret_cast<const d2*>(p.gpart), s * p.nv2 + c);
     reinterpret_cast<d2*>(p.g1)[c] = g;
     if (p.mode == 0) {
       const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];

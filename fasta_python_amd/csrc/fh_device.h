@@ -234,6 +234,20 @@ __device__ __forceinline__ void store_partial16(d2* base, uint32_t idx, d2 v) {
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)u, (short)0, 0x7FFFFFFF, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fh_u4, v), rs, idx * 16u, 0, 16);
 }
+__device__ __forceinline__ d2 load_partial2(const d2* p);
+// ... and the matching 16-byte load past L1 (`buffer_load_dwordx4 ... offen sc1`): the consumer's side of the same hand-off (CDNA4 guide,
+// Guideline 16: every load of handed-off bytes is an sc1 load to registers; 16-byte loads are in the measured set).  Half the load
+// instructions of load_partial2 in the finalisers, which add up tens to hundreds of team partials per column.
+__device__ __forceinline__ d2 load_partial16(const d2* base, uint32_t idx) {
+#ifdef FH_NARROW_PARTIALS
+  return load_partial2(base + idx);
+#endif
+  const unsigned long long a = (unsigned long long)(uintptr_t)base;
+  const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xFFFFFFFFu));
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)u, (short)0, 0x7FFFFFFF, 0x00020000);
+  return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16u, 0, 16));
+}
 __device__ __forceinline__ d2 load_partial2(const d2* p) {
   d2 v;
   v.x = load_partial(reinterpret_cast<const double*>(p));

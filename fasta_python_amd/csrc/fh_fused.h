@@ -584,10 +584,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     const bool mine = col < share && slice < slices && c < p.nv2;
     d2 g = {0.0, 0.0};
     if (mine) {
-      const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
       const uint32_t s1 = min((slice + 1u) * tps, p.nteams);
 #pragma unroll 8
-      for (uint32_t s = slice * tps; s < s1; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
+      for (uint32_t s = slice * tps; s < s1; ++s) g += load_partial16(reinterpret_cast<const d2*>(p.gpart), s * p.nv2 + c);
     }
     if (slices > 1) {                                // uniform over the workgroup
       __syncthreads();
@@ -602,8 +601,8 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
     if (p.mode == 0) {
       // xhat / xp were written by team 0 with plain stores earlier in THIS launch: read them back through sc1
       const d2 x0v = reinterpret_cast<const d2*>(p.x0)[c];
-      const d2 xpv = load_partial2(reinterpret_cast<const d2*>(p.xp) + c);
-      const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
+      const d2 xpv = load_partial16(reinterpret_cast<const d2*>(p.xp), c);
+      const d2 xhv = load_partial16(reinterpret_cast<const d2*>(p.xhat), c);
       d2 xav = {0.0, 0.0};
       if (p.accel) xav = reinterpret_cast<const d2*>(p.xacc0)[c];
       d2 x1v;

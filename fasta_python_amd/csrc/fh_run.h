@@ -205,14 +205,14 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
     if (load_x) {                          // first attempt of the launch
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
-        s_x0[k * FH_WG + tid] = load_partial2(reinterpret_cast<const d2*>(x0) + pc[k]);
-        s_xa[k * FH_WG + tid] = o.accelerate ? load_partial2(reinterpret_cast<const d2*>(xacc0) + pc[k]) : (d2){0.0, 0.0};
+        s_x0[k * FH_WG + tid] = load_partial16(reinterpret_cast<const d2*>(x0), pc[k]);
+        s_xa[k * FH_WG + tid] = o.accelerate ? load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]) : (d2){0.0, 0.0};
       }
       load_x = false;
     }
     if (load_g) {                          // after every accepted iteration: g1 was summed over all workgroups (phase B)
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) s_g0[k * FH_WG + tid] = load_partial2(reinterpret_cast<const d2*>(g0) + pc[k]);
+      for (int k = 0; k < PPT; ++k) s_g0[k * FH_WG + tid] = load_partial16(reinterpret_cast<const d2*>(g0), pc[k]);
       load_g = false;
     }
     d2 xq[XLDS ? 1 : PPT];
@@ -339,10 +339,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       const bool mine = col < share && slice < slices && c < p.nv2;
       d2 g = {0.0, 0.0};
       if (mine) {
-        const d2* gp = reinterpret_cast<const d2*>(p.gpart) + c;
         const uint32_t s1 = min((slice + 1u) * tps, G);
 #pragma unroll 8
-        for (uint32_t s = slice * tps; s < s1; ++s) g += load_partial2(gp + (uint64_t)s * p.nv2);
+        for (uint32_t s = slice * tps; s < s1; ++s) g += load_partial16(reinterpret_cast<const d2*>(p.gpart), s * p.nv2 + c);
       }
       if (slices > 1) {
         __syncthreads();
@@ -354,11 +353,11 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       }
       if (!mine || slice != 0) continue;
       store_partial16(reinterpret_cast<d2*>(g1), c, g);
-      const d2 x0v = load_partial2(reinterpret_cast<const d2*>(x0) + c);
-      const d2 xpv = load_partial2(reinterpret_cast<const d2*>(xp_out) + c);
-      const d2 xhv = load_partial2(reinterpret_cast<const d2*>(p.xhat) + c);
+      const d2 x0v = load_partial16(reinterpret_cast<const d2*>(x0), c);
+      const d2 xpv = load_partial16(reinterpret_cast<const d2*>(xp_out), c);
+      const d2 xhv = load_partial16(reinterpret_cast<const d2*>(p.xhat), c);
       d2 xav = {0.0, 0.0};
-      if (o.accelerate) xav = load_partial2(reinterpret_cast<const d2*>(xacc0) + c);
+      if (o.accelerate) xav = load_partial16(reinterpret_cast<const d2*>(xacc0), c);
       d2 x1v;
       x1v.x = bb_element(e, g.x, x0v.x, xpv.x, xav.x, xhv.x, 2u * c < p.n, u);
       x1v.y = bb_element(e, g.y, x0v.y, xpv.y, xav.y, xhv.y, 2u * c + 1u < p.n, u);

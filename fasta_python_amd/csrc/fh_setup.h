@@ -403,10 +403,9 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     for (int j = 0; j < NR; ++j) {
       g[j] = (d2){0.0, 0.0};
       if (mine) {
-        const d2* gp = reinterpret_cast<const d2*>(p.gpart) + (uint64_t)j * p.nv2 + c;
         const uint32_t s1 = min((slice + 1u) * tps, p.nteams);
 #pragma unroll 8
-        for (uint32_t s = slice * tps; s < s1; ++s) g[j] += load_partial2(gp + (uint64_t)s * NR * p.nv2);
+        for (uint32_t s = slice * tps; s < s1; ++s) g[j] += load_partial16(reinterpret_cast<const d2*>(p.gpart), (s * NR + j) * p.nv2 + c);
       }
       if (slices > 1) {                                // uniform over the workgroup
         __syncthreads();
