@@ -108,8 +108,13 @@ __device__ __forceinline__ double ft_sentinel() { return __hiloint2double((int)F
 // registers, two hot row buffers + the g1 slice + the x slice exceed what hipcc can keep out of scratch (300-600 spilled
 // registers, 2x slower); with it in LDS and NBO = 3-4 row buffers the loop compiles without spills and streams at the rate of
 // the narrow shapes (n = 131072: 5.36 -> 7.16 TB/s, profiles/r02_fused_wide.txt).
+// Workgroups per CU: one everywhere, except the float32-storage shapes of 8 and 16 members x 4 pieces with NBO = 4 (x and g1 slices of 32 registers
+// each, four 16-register row buffers: inside the 256-register budget of two waves per SIMD), where two co-resident workgroups per CU hide
+// each other's conversion, LDS and hand-off stalls.  All 2 x CUs workgroups are resident at once (two of these fit a CU and nothing else
+// runs), which is what the slot exchange and the grid barrier need; fh_host_launch.h:fused_wpc_of is the host's copy of this rule.
+template <int PPT, int TEAM, int XLDS, int F32> __host__ __device__ constexpr int fused_wpc() { return (F32 && TEAM >= 8 && PPT == 4 && !XLDS) ? 2 : 1; }
 template <int PPT, int NT, int PIPE, int TEAM, int XLDS = 0, int NBO = 0, int F32 = 0>   // NBO: number of row buffers (0 = the schedule's default); F32: float32-storage A
-__global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
+__global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_fused_dense(const FusedP p) {
   typedef typename PieceOf<F32>::type PT;
   constexpr int XD = xd2<F32>();                  // double pairs of x / g1 per 16-byte piece of A
   __shared__ __attribute__((aligned(16))) d2 s_x[XLDS ? PPT * XD * FH_WG : 1];
@@ -328,7 +333,13 @@ __global__ __launch_bounds__(FH_WG, 1) void k_fused_dense(const FusedP p) {
   };
   auto update_row = [&](const PT (&buf)[PPT], double rv) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) piece_axpy(buf[k], rv, ga[k]);
+    for (int k = 0; k < PPT; ++k) {
+      PT a = buf[k];
+      // two workgroups per CU (256 registers): make the piece opaque here, or hipcc keeps the float64 conversions that dot_row made of it
+      // PIPE rows earlier alive until this update -- twice the registers of the row buffers themselves, i.e. scratch -- instead of converting again
+      if constexpr (fused_wpc<PPT, TEAM, XLDS, F32>() == 2) asm volatile("" : "+v"(a));
+      piece_axpy(a, rv, ga[k]);
+    }
   };
   // ---------------- FISTA: every team needs this step's restart dot before its first row (the gradient is taken at the
   // extrapolated z): the members exchange their slice sums through the team's extra slot line, summed in member order

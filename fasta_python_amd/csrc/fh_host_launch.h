@@ -315,6 +315,15 @@ static FusedShape fused_shape_for(uint64_t n, uint64_t ld, int f32, int variant,
       if (team > 1 && ppt < 5) ppt = 5;          // (cannot happen: pieces > (team/2)*256*8 already means ppt >= 5)
       const int xl = ppt >= 5 ? 1 : 0;
       sh = {ppt, team, 1, xl, xl ? (ppt <= 6 ? 4 : 3) : 0};
+      // A full 8-piece shape of 4 or 8 members (n in (28672, 32768] and (57344, 65536] = BASELINE config 2's
+      // width) runs as TWICE the members x 4 pieces with TWO workgroups per CU (fh_fused.h:fused_wpc) and the x slice back in registers.
+      // A float32 piece costs four conversions and eight float64 multiply-adds, twice the issue slots per byte of the float64 kernel, and
+      // ONE wave per SIMD has nobody to hide its LDS, conversion and hand-off stalls behind; two have each other (x + g1 slices 64
+      // registers, four 16-register row buffers: 219 of the 256 registers, no scratch in the loops).  profiles/r05_f32_shapes.txt:
+      // 65536^2 2.577 -> 2.49-2.53 ms, 65536 x 32768 1.31-1.34 -> 1.26 ms.  (variant bit 8: the one-per-CU shapes, for A/B)
+      // Teams of 1 and 2 (n <= 16384) stay one per CU: there the launch is short and the doubled grid barrier and hand-off cost more than
+      // the second wave hides (8192^2: 91 -> 111 us, 16384^2: 212 -> 230 us; 32768^2 equal, 65536 x 32768 and 65536^2 3-5 % faster).
+      if (ppt == 8 && team >= 4 && team <= 8 && !(variant & 8) && ncu % (2 * team) == 0) sh = {4, 2 * team, 1, 0, 4};
       break;
     }
   } else if (pieces <= (uint64_t)1 * FH_WG * 8 && !(variant & 8)) {
@@ -348,6 +357,8 @@ static FusedShape fused_shape_for(uint64_t n, uint64_t ld, int f32, int variant,
   if (!sh.ppt || ncu < sh.team || ncu % sh.team) return none;     // one workgroup per CU, whole teams only
   return sh;
 }
+// workgroups per CU of a shape (fh_fused.h:fused_wpc): two for the float32-storage shape of 16 members x <= 4 pieces, else one
+static int fused_wpc_of(const FusedShape& sh, int f32) { return (f32 && sh.team >= 8 && sh.ppt == 4 && !sh.xlds) ? 2 : 1; }
 static const FusedEntry* fused_lookup(const FusedShape& sh, int f32) {
   for (const FusedEntry& e : kFusedTable)
     if (e.ppt == sh.ppt && e.pipe == sh.pipe && e.team == sh.team && e.xlds == sh.xlds && e.nbo == sh.nbo && e.f32 == f32) return &e;
@@ -402,7 +413,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
   p.ldp = (uint32_t)(c->ld / (c->f32 ? 4 : 2));
   p.nv2 = p.ld2 * (c->f32 ? 2u : 1u);
-  p.nteams = (uint32_t)(fused_ncu(c) / sh.team);
+  p.nteams = (uint32_t)(fused_ncu(c) * fused_wpc_of(sh, c->f32) / sh.team);
   // few rows: fewer teams (at least FUSED_MIN_ROWS rows each when possible, and a multiple of 8 teams so that the members of
   // a team stay on one XCD): a smaller grid barrier and fewer g1 partials to sum in the epilogue
   if (c->fused_min_rows > 0) {

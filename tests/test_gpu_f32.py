@@ -89,7 +89,9 @@ def _state(op, b, mu, x0, g0=None):
 @pytest.mark.parametrize("m,n", [(1, 40), (37, 512), (60, 1024), (300, 2048), (90, 5120), (70, 6000), (50, 7000), (64, 8192),   # one member: 1, 2, 4, 5..8 pieces per lane
                                  (130, 9000), (50, 12000), (40, 15000), (33, 16384),              # 2 members
                                  (60, 20000), (35, 32768), (30, 50000), (25, 65536),               # 4 and 8 members
-                                 (20, 81920), (18, 100000), (16, 120000), (15, 131072)])           # 16 members
+                                 (20, 81920), (18, 100000), (16, 120000), (15, 131072),            # 16 members
+                                 # full 8-piece widths: twice the members x 4 pieces, two workgroups per CU (512 co-resident workgroups)
+                                 (300, 30000), (1030, 32768), (40, 57345), (600, 60000), (700, 65536)])
 def test_fused_step_equals_two_launch_step_in_float32_storage(m, n):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
