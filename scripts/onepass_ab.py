@@ -1,3 +1,6 @@
+"""Per-launch time of the one-pass kernel (and of K-fwd / K-adj at 65536^2) across the shapes a build serves: best of three solves,
+HIP events.  Run it once per library on ONE box for an A/B: FASTA_HIP_LIB=fasta_python_amd/libfasta_hip_narrow.so python scripts/onepass_ab.py
+(`make -C fasta_python_amd/csrc narrow` builds that library: 8-byte hand-off stores / loads instead of the 16-byte ones)."""
 import os, sys, time, warnings
 sys.path.insert(0, os.getcwd())
 import numpy as np
