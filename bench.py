@@ -618,6 +618,24 @@ def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096)), iters
                     steps_on_device = solver.device_steps
                 rates[name] = {"iterations/s": best, "us_per_iteration": 1e6 / best, "iterations_inside_persistent_launches": steps_on_device}
             rates["speedup"] = rates["device_loop"]["iterations/s"] / rates["per_iteration_launches"]["iterations/s"]
+            if (m, n) == (512, 1024):
+                # BASELINE config 1 as BASELINE states it: the same problem on the NumPy CPU path -- the product's generic host loop with the
+                # reference's closure forms (examples/sparse_least_squares.py:41-44) on a host copy of the matrix; no GPU involved
+                Ah = A.host_rows(0, m)
+                mu = 0.02
+                best = 0.0
+                for _ in range(repeats):
+                    np.random.seed(3)
+                    t0 = time.perf_counter()
+                    with warnings.catch_warnings(), np.errstate(all="ignore"):
+                        warnings.simplefilter("ignore")
+                        r = fa.fasta(Ah, Ah.T, lambda z: .5 * np.linalg.norm((z - b).ravel()) ** 2, lambda z: z - b,
+                                     lambda x: mu * np.linalg.norm(x.ravel(), 1), lambda x, t: fa.proximal.shrink(x, t * mu),
+                                     np.zeros(n), verbose=False, max_iters=iters, tolerance=0.0, backend="numpy")
+                    k = r.iteration_count
+                    best = max(best, k / (r.times[k] - r.times[0]))
+                rates["numpy_host_loop"] = {"iterations/s": best, "us_per_iteration": 1e6 / best,
+                                            "note": "BASELINE config 1: fasta(A, A.T, f, gradf, g, proxg, x0) with Python closures on host arrays (generic loop, bit-identical to the reference)"}
             out[f"{m}x{n}"] = rates
         finally:
             A.close()
