@@ -1,5 +1,6 @@
-"""Soak run of the one-pass kernels: thousands of consecutive launches at full size, checking that the bounded-spin
-hand-offs never time out, that per-iteration time stays flat and that two identical solves are bitwise equal (GPU box)."""
+"""Soak run of the kernels with cross-workgroup hand-offs: thousands of consecutive launches at full size (one-pass dense and stencil kernels, the
+multi-workgroup level search, the set-up kernel) and tens of thousands of iterations inside persistent launches (the device loop), checking that the
+bounded spins never time out, that per-iteration time stays flat and that two identical solves are bitwise equal (GPU box)."""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -35,6 +36,64 @@ def dense(storage):
         b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
         return A, fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n), dict(adaptive=True)
     return make
+
+def dense_prox(kind):
+    """round 5: the l1-ball / l-infinity prox -- every forward launch is preceded by the multi-workgroup level search (csrc/fh_prox.h)"""
+    def make():
+        m = n = 65536
+        A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
+        x_true = synthetic.sparse_signal(n, 1)
+        b = synthetic.lasso_observation(A, x_true, 2, 0.01)
+        reg = fa.L1Ball(0.8 * float(np.abs(x_true).sum())) if kind == "l1ball" else fa.LinfProx(0.02)
+        return A, fa.LeastSquares(b), reg, np.zeros(n), dict(adaptive=True)
+    return make
+
+def device_loop(m, n, iters, per_launch):
+    """round 5: the FBS loop on the device (fh_run): `iters` iterations in persistent launches of `per_launch`, twice; every iteration must have run
+    inside a persistent launch (no timeout, no fall-back) and the two solves must be bitwise identical"""
+    sols = []
+    for rep in range(2):
+        A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
+        try:
+            b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
+            np.random.seed(3)
+            t0 = time.perf_counter()
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+                c = fa.fasta(A, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), verbose=False, max_iters=iters, tolerance=0.0, device_iters=per_launch, backend="hip")
+            dt = time.perf_counter() - t0
+            assert c.device_steps == c.iteration_count == iters, (c.device_steps, c.iteration_count)
+            sols.append((c.solution.copy(), c.residuals.copy(), c.stepsizes.copy()))
+            print(f"device loop {m}x{n} run {rep}: {c.iteration_count} iterations in launches of {per_launch}, {c.backtracks} backtracks, {c.iteration_count / dt:9.1f} it/s (whole call)", flush=True)
+        finally:
+            A.close()
+    same = all(np.array_equal(a, b_, equal_nan=True) for a, b_ in zip(sols[0], sols[1]))
+    print(f"device loop {m}x{n}: two runs bitwise identical: {same}", flush=True)
+    assert same
+
+def setups(calls):
+    """round 5: the one-read set-up (fh_setup) over and over on one context: one one-pass launch per call, never the three-pass fall-back, same scalars every time"""
+    m = n = 65536
+    A = fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
+    try:
+        c = A.ctx
+        b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
+        c.set_loss_lsq(b); c.set_prox(hip.PROX_SHRINK, 0.02)
+        rng = np.random.RandomState(0)
+        c.set_vector(hip.VEC_T0, rng.randn(n)); c.set_vector(hip.VEC_T1, rng.randn(n)); c.set_vector(hip.VEC_X0, np.zeros(n))
+        first, t0 = None, time.perf_counter()
+        c.timing_reset(); c.timing_enable(True)
+        for _ in range(calls):
+            s = c.setup().copy()
+            if first is None: first = s
+            assert np.array_equal(s, first), "fh_setup is not repeatable"
+        c.timing_enable(False)
+        ms, cnt = c.timing_get(hip.K_FUSED)
+        assert cnt == calls, f"{cnt} one-pass launches for {calls} calls: some took the three-pass fall-back"
+        print(f"fh_setup x {calls} at {m}x{n}: {cnt} one-pass launches ({ms / cnt:.3f} ms each), {(time.perf_counter() - t0) / calls * 1e3:.3f} ms per call, scalars identical every time", flush=True)
+    finally:
+        A.close()
 
 def dense_blocks(m, blocks):
     """the single-call multi-device form with all row blocks on this GPU (ShardedDenseMatrixMap, repeated device id)"""
@@ -100,7 +159,18 @@ def side_by_side(cus, iters):
           f"no timeout; bitwise identical to the solve that ran alone: {same}", flush=True)
     assert same
 
-which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "tv", "tvacc", "blocks8", "config5", "tvring", "tvslots", "pair128"]
+# (tvring / tvslots: the experimental library only -- FASTA_HIP_LIB=fasta_python_amd/libfasta_hip_experimental.so python scripts/soak.py tvring,tvslots)
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "l1ball", "linf", "devloop", "setup", "tv", "tvacc", "blocks8", "config5", "pair128"]
+if "devloop" in which:
+    device_loop(4096, 4096, 20000, 64)
+    device_loop(512, 1024, 50000, 512)
+    device_loop(2048, 3000, 20000, 7)
+if "setup" in which:
+    setups(300)
+if "l1ball" in which:
+    soak("l1-ball constrained LASSO 65536^2 (level search every launch)", dense_prox("l1ball"), 1500)
+if "linf" in which:
+    soak("least squares + l-infinity prox 65536^2 (level search every launch)", dense_prox("linf"), 1500)
 if "pair128" in which:
     side_by_side(128, 600)
 if "tvring" in which:
