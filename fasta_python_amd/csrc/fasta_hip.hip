@@ -964,13 +964,18 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
 // ---- the loop on the device (csrc/fh_run.h) --------------------------------------------------------------------------------------------
 struct RunEntry { int ppt; void (*kernel)(const RunP); };
 static const RunEntry kRunTable[] = {{1, k_run_dense<1>}, {2, k_run_dense<2>}, {4, k_run_dense<4>}, {5, k_run_dense<5>},
-                                     {6, k_run_dense<6>}, {7, k_run_dense<7>}, {8, k_run_dense<8>}};
+                                     {6, k_run_dense<6>}, {7, k_run_dense<7>}, {8, k_run_dense<8>},
+                                     {10, k_run_dense<10>}, {12, k_run_dense<12>}, {14, k_run_dense<14>}};
+// (16 pieces per lane -- n in (7168, 8192] -- were measured and left out: 8192^2 158 us per iteration against 140 us on the per-iteration path,
+//  profiles/r05_device_loop.txt)
 static const RunEntry* run_entry(fh_ctx* c) {
   if (c->op != OP_DENSE || c->f32 || row_sharded(c) || !c->shards.empty()) return nullptr;
   if (c->prox_kind != FH_PROX_IDENTITY && c->prox_kind != FH_PROX_SHRINK && c->prox_kind != FH_PROX_NONNEG && c->prox_kind != FH_PROX_BOX) return nullptr;
-  const FusedShape sh = fused_shape(c);
-  if (sh.team != 1 || sh.xlds) return nullptr;
-  for (const RunEntry& e : kRunTable) if (e.ppt == sh.ppt) return &e;
+  // a workgroup owns whole rows: 16-byte pieces per lane = the first table entry that covers the row (lanes past the row's end re-read its last piece)
+  const uint64_t pieces = round_up(c->n, 16) / 2;
+  if (c->ld % 2 || pieces == 0 || pieces > (uint64_t)FH_WG * 14) return nullptr;
+  const int need = (int)((pieces + FH_WG - 1) / FH_WG);
+  for (const RunEntry& e : kRunTable) if (e.ppt >= need) return &e;
   return nullptr;
 }
 extern "C" int fh_run_supported(fh_ctx* c, int* yes) {

@@ -7,7 +7,10 @@
 // rules (stopping.py:6-51) -- is decided on the device, identically by EVERY workgroup from the same sums (no broadcast step), and the
 // histories of the iterations go back to the host in one block at the end.
 //
-// Shapes: a workgroup owns whole rows (n <= 4096: the "team of one" shape of fh_fused.h), one workgroup per CU, all resident.
+// Shapes: a workgroup owns whole rows, one workgroup per CU, all resident: n <= 4096 is the "team of one" shape of fh_fused.h (1-8 pieces per
+// lane); n in (4096, 7168] runs 10-14 pieces per lane with three row buffers (the wide-row register budget of fh_fused.h) and keeps only x0 and
+// the prox output in LDS -- the gradient and x_accel0 are re-read from L2 in every attempt.  Gains there: 5000^2 +40 %, 6000^2 +16 %, 7000^2 +3 %
+// over the per-iteration path; 16 pieces (n up to 8192) lose 12 % at 8192^2 and are not instantiated (profiles/r05_device_loop.txt).
 // One attempt (an iteration, or a backtracking retry of it):
 //   phase A   every workgroup: xhat = x0 - tau g0, xprox = prox(xhat) for the WHOLE n side (so every workgroup holds the forward sums
 //             <Dx,g0>, ||Dx||^2, ... and the restart dot itself: nothing to exchange), then its rows: z_i = a_i . xprox, the gradient
@@ -20,11 +23,11 @@
 // Vectors that one workgroup writes and another reads in the NEXT attempt (g1, x1, xprox, xhat) are stored write-through (sc1) and
 // loaded past L1 (sc1), as the CDNA4 guide's Guideline 16 prescribes for in-launch hand-offs; barriers are generation counters with
 // bounded spins (a timeout ends the launch with `stopped = 3`).
-// Measured and NOT shipped (round 5): rows of 4096 < n <= 8192 columns with 512-thread workgroups (two waves per SIMD, whole rows per
-// workgroup, x0 / g0 in LDS): correct, but hipcc spills ~210 registers per lane at two waves per SIMD and an iteration at 8192^2 takes
-// 209 us against 136 us on the per-iteration path (profiles/r05_device_loop.txt).  n <= 4096 it is.
+// Measured and NOT shipped (round 5): rows of 4096 < n <= 8192 columns with 512-thread workgroups (two waves per SIMD, x0 / g0 in LDS):
+// correct, but hipcc spills ~210 registers per lane at two waves per SIMD and an iteration at 8192^2 takes 209 us against 136 us on the
+// per-iteration path (profiles/r05_device_loop.txt).
 // Not here (the caller keeps the per-iteration path): Python hooks (stop_rule other than the four, func, record_iterates, verbose),
-// the level-search prox kinds, float32 storage, row sharding, wider rows.
+// the level-search prox kinds, float32 storage, row sharding, rows wider than 7168 columns.
 #pragma once
 #include "fh_fused.h"
 
@@ -109,13 +112,14 @@ __device__ __forceinline__ double fr_pymax(double a, double b) { return b > a ? 
 template <int PPT>
 __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
   typedef d2 PT;
-  constexpr bool XLDS = PPT >= 7;          // 7-8 pieces per lane: the dot products read the prox'd x slice from LDS, or the persistent loop spills
+  constexpr bool XLDS = PPT >= 7;          // 7+ pieces per lane: the dot products read the prox'd x slice from LDS, or the persistent loop spills
+  constexpr bool BIG = PPT > 8;            // n in (4096, 7168]: only x0 and the prox output fit the LDS; g0 and x_accel0 come from L2 in every attempt
   // The n-side state of the solve lives in LDS, one copy per workgroup (every workgroup forms the whole forward point and prox itself,
   // so it can also keep x0, x_accel0 and the last prox output across attempts): between two iterations only the new gradient -- summed
   // over all workgroups -- has to be read back; a backtracking retry reads nothing.  PPT x 4 KiB each (PPT = 8: 128 KiB of the 160).
   __shared__ __attribute__((aligned(16))) d2 s_x0[PPT * FH_WG];     // x0
-  __shared__ __attribute__((aligned(16))) d2 s_g0[PPT * FH_WG];     // gradient at x0
-  __shared__ __attribute__((aligned(16))) d2 s_xa[PPT * FH_WG];     // x_accel0 (FISTA)
+  __shared__ __attribute__((aligned(16))) d2 s_g0[BIG ? 1 : PPT * FH_WG];     // gradient at x0
+  __shared__ __attribute__((aligned(16))) d2 s_xa[BIG ? 1 : PPT * FH_WG];     // x_accel0 (FISTA)
   __shared__ __attribute__((aligned(16))) d2 s_x[PPT * FH_WG];      // this attempt's prox output
   __shared__ __attribute__((aligned(16))) d2 s_fin[FH_WG];
   __shared__ __attribute__((aligned(16))) double s_part2[2][4];
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       for (int k = 0; k < PPT; ++k) buf[k] = load_stream<0>(src + pc[k]);
     }
   };
-  constexpr int NB = PPT >= 7 ? 4 : (PPT >= 5 ? 5 : 6);       // row buffers: what stays out of scratch inside the persistent loop
+  constexpr int NB = BIG ? 3 : (PPT >= 7 ? 4 : (PPT >= 5 ? 5 : 6));       // row buffers: what stays out of scratch inside the persistent loop
   const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
   const RunOpts o = p.o;
 
@@ -206,13 +210,15 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         s_x0[k * FH_WG + tid] = load_partial16(reinterpret_cast<const d2*>(x0), pc[k]);
-        s_xa[k * FH_WG + tid] = o.accelerate ? load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]) : (d2){0.0, 0.0};
+        if constexpr (!BIG) s_xa[k * FH_WG + tid] = o.accelerate ? load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]) : (d2){0.0, 0.0};
       }
       load_x = false;
     }
     if (load_g) {                          // after every accepted iteration: g1 was summed over all workgroups (phase B)
+      if constexpr (!BIG) {
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) s_g0[k * FH_WG + tid] = load_partial16(reinterpret_cast<const d2*>(g0), pc[k]);
+        for (int k = 0; k < PPT; ++k) s_g0[k * FH_WG + tid] = load_partial16(reinterpret_cast<const d2*>(g0), pc[k]);
+      }
       load_g = false;
     }
     d2 xq[XLDS ? 1 : PPT];
@@ -220,7 +226,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
       const uint32_t c = c0 + k * FH_WG;
-      const d2 x0v = s_x0[k * FH_WG + tid], g0v = s_g0[k * FH_WG + tid], xav = s_xa[k * FH_WG + tid];      // (each lane reads back only its own entries)
+      const d2 x0v = s_x0[k * FH_WG + tid];                                                                  // (each lane reads back only its own entries)
+      d2 g0v, xav = {0.0, 0.0};
+      if constexpr (BIG) {
+        g0v = load_partial16(reinterpret_cast<const d2*>(g0), pc[k]);
+        if (o.accelerate) xav = load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]);
+      } else { g0v = s_g0[k * FH_WG + tid]; xav = s_xa[k * FH_WG + tid]; }
       d2 xh, xp;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -468,12 +479,12 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       const d2 xpv = s_x[k * FH_WG + tid];
       d2 x1v = xpv;
       if (o.accelerate) {
-        const d2 xav = s_xa[k * FH_WG + tid];
+        const d2 xav = BIG ? load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]) : s_xa[BIG ? 0 : k * FH_WG + tid];
         x1v.x = extrapolate(xpv.x, xav.x, coef); x1v.y = extrapolate(xpv.y, xav.y, coef);
         const uint32_t c = c0 + k * FH_WG;
         if (!(2u * c < p.n)) x1v.x = 0.0;
         if (!(2u * c + 1u < p.n)) x1v.y = 0.0;
-        s_xa[k * FH_WG + tid] = xpv;
+        if constexpr (!BIG) s_xa[k * FH_WG + tid] = xpv;
       }
       s_x0[k * FH_WG + tid] = x1v;
     }

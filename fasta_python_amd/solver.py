@@ -118,7 +118,7 @@ class FBSolver:
         K-fwd/K-adj (same results).
         device_iters = K > 0 (opt-in) -- run the loop itself on the device, K iterations per persistent launch (`HipContext.run`,
         csrc/fh_run.h): backtracking, FISTA, the Barzilai-Borwein rule and the stop rule are decided there, the histories come back
-        in one block.  For short iterations (n <= 4096), where launches and host round trips dominate.  Taken only when nothing
+        in one block.  For short iterations (n <= 7168), where launches and host round trips dominate.  Taken only when nothing
         needs the host between two iterations -- `stop_rule` is one of the four of fasta/stopping.py, no `func`, no
         `record_iterates`, `verbose` off -- and the context has a kernel for it; otherwise the per-iteration path runs (same
         results, `device_steps` stays 0).  `times[i]` within one launch are interpolated between its start and its end."""

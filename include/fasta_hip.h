@@ -252,7 +252,7 @@ int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* sca
  *   history max_steps records of FH_RUN_HIST doubles: residual, norm_residual, stepsize, f_hist[i+1], objective, backtracks of the
  *           iteration, alpha0, 1 if the iterate became the best one
  *   steps_done  iterations executed (fewer than max_steps when the stop rule fired: state->stopped = 1)
- * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 4096 on a
+ * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 7168 on a
  * single-device context, a scalar-separable prox without level search, every CU free for one resident workgroup).                 */
 #define FH_RUN_HIST 8
 #define FH_RUN_WINDOW_MAX 64

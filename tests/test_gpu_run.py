@@ -66,7 +66,8 @@ MODES = {"adaptive": dict(), "accelerated": dict(adaptive=False, accelerate=True
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))
-@pytest.mark.parametrize("m,n", [(300, 4096), (96, 160), (700, 2000), (1500, 1000), (40, 3000)])
+@pytest.mark.parametrize("m,n", [(300, 4096), (96, 160), (700, 2000), (1500, 1000), (40, 3000),
+                                 (300, 4100), (520, 5000), (130, 6000), (64, 7000), (600, 7168)])      # n > 4096: 10 / 10 / 12 / 14 / 14 pieces per lane, g0 and x_accel0 from L2
 def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     rng = np.random.RandomState(m + n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -86,7 +87,9 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     for f in ("residuals", "norm_residuals", "stepsizes"):
         np.testing.assert_allclose(getattr(dev, f)[:kk], getattr(host, f)[:kk], rtol=1e-6, atol=1e-300, err_msg=f)
     np.testing.assert_allclose(dev.objectives[:k + 1], host.objectives[:k + 1], rtol=1e-8)
-    np.testing.assert_allclose(dev.solution, host.solution, rtol=1e-5, atol=1e-9)
+    # (atol: the signal's entries are 1; entries of 1e-4 that sit next to the shrink threshold after 120 iterations move by ~1e-8 with the summation
+    # order -- the per-iteration path sums n = 8192 in teams of two, the device loop in one workgroup -- in the backtracking-heavy modes)
+    np.testing.assert_allclose(dev.solution, host.solution, rtol=1e-5, atol=1e-7 if n > 4096 else 1e-9)
     P = pr.sparse_least_squares_from(A, b, 0.02)
     np.random.seed(5)
     with warnings.catch_warnings():
@@ -98,7 +101,7 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     np.testing.assert_allclose(dev.residuals[:kk], want.residuals[:kk], rtol=1e-6)
     np.testing.assert_allclose(dev.stepsizes[:kk], want.stepsizes[:kk], rtol=1e-6)
     np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
-    np.testing.assert_allclose(dev.solution, want.solution, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(dev.solution, want.solution, rtol=1e-5, atol=1e-7 if n > 4096 else 1e-9)
 
 
 @pytest.mark.parametrize("reg", ["nonneg", "box", "none"])
@@ -149,5 +152,36 @@ def test_options_that_need_the_host_between_iterations_keep_the_per_iteration_pa
         ref = _solve(A, b, fa.Shrink(0.02), np.zeros(n), max_iters=30, **extra)
         assert got.device_steps == 0 and got.iteration_count == ref.iteration_count
         assert np.array_equal(got.residuals, ref.residuals) and np.array_equal(got.solution, ref.solution)
-    wide = _solve(rng.randn(50, 9000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(9000), device_iters=8, max_iters=10)     # n > 4096: no kernel
+    wide = _solve(rng.randn(50, 9000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(9000), device_iters=8, max_iters=10)     # n > 7168: no kernel
     assert wide.device_steps == 0 and wide.iteration_count == 10
+
+
+def test_operators_without_a_device_loop_keep_the_per_iteration_path():
+    """device_iters on operators fh_run has no kernel for -- float32 storage, in-process row blocks, the l1-ball prox (its level search is a launch
+    of its own), the stencil -- must run the ordinary loop and produce its bits."""
+    rng = np.random.RandomState(6)
+    m, n = 240, 900
+    A = rng.randn(m, n) / 30
+    b = rng.randn(m)
+    x0 = np.zeros(n)
+
+    def both(make_op, reg):
+        out = []
+        for kw in (dict(device_iters=8), {}):
+            op = make_op()
+            try:
+                np.random.seed(5)
+                ls = fa.LeastSquares(b)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out.append(fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, max_iters=25, tolerance=0.0, backend="hip", **kw))
+            finally:
+                op.close()
+        got, ref = out
+        assert got.device_steps == 0 and got.iteration_count == ref.iteration_count == 25
+        assert np.array_equal(got.residuals, ref.residuals) and np.array_equal(got.solution, ref.solution)
+
+    both(lambda: fa.DenseMatrixMap(A, storage="f32"), fa.Shrink(0.02))
+    both(lambda: fa.ShardedDenseMatrixMap(A, devices=[0, 0, 0]), fa.Shrink(0.02))
+    both(lambda: fa.DenseMatrixMap(A), fa.L1Ball(3.0))
+    both(lambda: fa.DenseMatrixMap(A), fa.LinfProx(0.05))
