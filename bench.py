@@ -587,7 +587,7 @@ def natural_runs(A, n, m_total):
     return out
 
 
-def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096)), iters=512, per_launch=64, repeats=3):
+def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096), (6000, 6000)), iters=512, per_launch=64, repeats=3):
     """fasta(..., device_iters=K) -- the FBS loop itself in persistent launches (fh_run, csrc/fh_run.h) -- against the per-iteration path on
     the reference's own problem sizes (its examples are 200 x 1000 ... 1000 x 2000; SURVEY.md 8(d) config 1 is 512 x 1024), where a launch and
     the host round trip cost more than the iteration's arithmetic.  Same synthetic LASSO recipe as the headline; best of `repeats` solves."""
