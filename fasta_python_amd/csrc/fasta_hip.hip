@@ -53,7 +53,7 @@ static const FusedEntry kFusedTable[] = {
 #undef FUSED_INST_2
 #undef FUSED_INST_3
 
-// the three-column set-up kernel's variants: the same scheme, fh_setup_instances.inc / fh_setup_part.hip
+// the set-up kernel's variants: the same scheme, fh_setup_instances.inc / fh_setup_part.hip
 #ifndef FH_SINGLE_TU
 #define FH_SETUP_DECLARE(P, PI, T, NT, NR) extern template __global__ void k_setup_dense<P, PI, T, NT, NR>(const SetupP);
 #define SETUP_INST_0 FH_SETUP_DECLARE
@@ -595,7 +595,7 @@ extern "C" int fh_init(fh_ctx* c, double* scalars) {
 // x0 in FH_VEC_X0.  Leaves the state fh_init leaves (z, g0, best iterate, acceleration history) and returns fh_init's scalars plus
 // FH_S_DG2 = ||A^H grad f(A T0) - A^H grad f(A T1)||^2 and FH_S_DX2 = ||T0 - T1||^2 (the two norms of :110); FH_VEC_T2 / FH_VEC_T3 are
 // scratch afterwards (the one-read kernel forms the gradient difference as A^T A (T0 - T1): csrc/fh_setup.h).
-// Where the three-column kernel of csrc/fh_setup.h has a shape for this operator (dense float64, least squares, n <= 65536, single context, large
+// Where the set-up kernel of csrc/fh_setup.h has a shape for this operator (dense float64, least squares, n <= 65536, single context, large
 // enough for the one-pass kernel to pay) all of it comes from ONE read of A; everywhere else -- and after a hand-off timeout -- it is
 // the three passes fh_gradient_at x 2 + fh_init, so the call is always available and its results agree to summation-order rounding
 // (bit for bit where the one-pass kernel serves the three passes too).

@@ -1,19 +1,22 @@
 // fh_setup.h -- the solver's whole SET-UP from ONE read of A (round 5).
 //
 // Before its first iteration the reference applies A and A^H three times (fasta/__init__.py:100-113: the two Lipschitz probes
-// gradf(x1), gradf(x2) with x1, x2 ~ randn; :135-137: z = A x0, f(z), gradf at x0).  The three right-hand sides are independent, so a
-// three-column instantiation of the one-pass scheme of fh_fused.h serves them from a single read of the matrix: a member of a team
+// gradf(x1), gradf(x2) with x1, x2 ~ randn; :135-137: z = A x0, f(z), gradf at x0).  The right-hand sides are independent, so a
+// multi-column instantiation of the one-pass scheme of fh_fused.h serves them from a single read of the matrix: a member of a team
 // keeps its piece of rows t .. t+D in registers (the SAME team shapes, row ranges and buffers as k_fused_dense<PPT, 1, D, TEAM>),
-// forms THREE partial dot products per row against three x slices held in LDS, the team exchanges them through three slot lines
-// per row, and every wave applies three rank-1 updates to three register-resident slices of the three gradients.
-//   * the three polls of a row run in PARALLEL: wave 1 posts the member's three partials, waves 0, 2 and 3 each poll one
+// forms NR partial dot products per row against NR x slices held in LDS, the team exchanges them through NR slot lines per row, and
+// every wave applies NR rank-1 updates to NR register-resident gradient slices.
+//   * SHIPPED: NR = 2.  For the least-squares loss the probes enter only through their difference, grad(x1) - grad(x2) = A^T A (x1 - x2),
+//     so the columns are d = x1 - x2 (homogeneous residual) and x0 (residual z - b); the first version carried all three columns
+//     (NR = 3, still instantiable) and spilled into the row loop: 7.8 ms against 5.0-5.5 ms (profiles/r05_setup_cost.txt);
+//   * the polls of a row run in PARALLEL: wave 1 posts the member's partials, waves 0 and 2 (and 3 for NR = 3) each poll one
 //     right-hand side (scalar loads, bounded) and broadcast its gradient factor -- a trip is no longer than k_fused_dense's;
 //   * every right-hand side is summed in exactly the order k_fused_dense sums it (pieces in lane order, DPP wave sum, waves
-//     0..3, members 0..TEAM-1, teams 0..nteams-1 with the same slice split in the finaliser), so T2 / T3 / g0 / z / f come out
-//     BIT-IDENTICAL to three separate one-pass launches (fh_gradient_at x 2 + fh_init) -- tests/test_gpu_setup.py;
-//   * the finaliser also forms ||grad1 - grad2||^2 and (team 0's prologue) ||x1 - x2||^2: the two norms of :110 come back with
-//     the scalar block, no further launch.
-// Shapes: float64 storage, PPT <= 8 (n <= 65536): 3 x PPT x 4 KiB of LDS for the x slices, 3 x PPT x 4 registers for the gradient
+//     0..3, members 0..TEAM-1, teams 0..nteams-1 with the same slice split in the finaliser), so g0 / z / f come out BIT-IDENTICAL
+//     to fh_init's one-pass launch, and L agrees with the three-pass value to ~1e-15 relative -- tests/test_gpu_setup.py;
+//   * the finaliser also forms ||A^T A d||^2 and (team 0's prologue) ||x1 - x2||^2: the two norms of :110 come back with the scalar
+//     block, no further launch.
+// Shapes: float64 storage, PPT <= 8 (n <= 65536): NR x PPT x 4 KiB of LDS for the x slices, NR x PPT x 4 registers for the gradient
 // slices.  Wider rows, float32 storage, the logistic loss and row-sharded contexts keep the three-pass set-up (fh_setup falls back by
 // itself).  The slots are filled with the sentinel by the host before the launch (one launch per solve: no re-arming).
 #pragma once

@@ -1,4 +1,4 @@
-// fh_setup_part.hip -- one group of explicit instantiations of the three-column set-up kernel (see fh_setup_instances.inc).
+// fh_setup_part.hip -- one group of explicit instantiations of the multi-column set-up kernel (see fh_setup_instances.inc).
 // Compiled once per group with -DFH_PART=0..1; fasta_hip.hip only declares these variants `extern template`.
 #include "fh_setup.h"
 

@@ -155,7 +155,7 @@ class FBSolver:
             c.set_vector(hip.VEC_T1, p2)
         c.set_vector(hip.VEC_X0, self.x0)
         if probes and hasattr(c, "setup"):
-            # probes and the initial pass (:135-137) in ONE call: one read of a dense A where the three-column kernel has a shape
+            # probes and the initial pass (:135-137) in ONE call: one read of a dense A where the set-up kernel (csrc/fh_setup.h) has a shape
             s = c.setup()
             L = _sqrt(s[hip.S_DG2]) / _sqrt(s[hip.S_DX2])
             tau0 = (2 / L) / 10
