@@ -195,3 +195,47 @@ def test_random_shapes_modes_and_row_blocks_in_process(seed):
     # 1e-6; the Barzilai-Borwein step is a quotient ||Dx||^2 / <Dx, Dg> whose denominator cancels on these tiny random instances --
     # steps of 10..20 x the usual -- so an individual step size may differ in its 5th digit while the iterates stay within 1e-5)
     _same(got, want, rtol=1e-5, rtol_steps=2e-4)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shapes_modes_and_launch_lengths_with_the_loop_on_the_device(seed):
+    """The same random corner of the option space with `device_iters` = a random launch length: the controller of csrc/fh_run.h (backtracking,
+    restart, Barzilai-Borwein, residuals, best iterate, stop rule) against the oracle loop, zero and non-zero starts, ragged shapes up to the widest
+    row the device loop takes (7168 columns), every built-in stop rule."""
+    from fasta_python_amd import stopping
+    rng = np.random.RandomState(3000 + seed)
+    wide = seed % 4 == 3
+    m = int(rng.randint(1, 260))
+    n = int(rng.randint(4097, 7169)) if wide else int(rng.randint(1, 600))
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = rng.randn(m)
+    x0 = rng.randn(n) * (0.1 if seed % 2 else 0.0)
+    kind = ("shrink", "nonneg")[seed % 2]
+    adaptive, accelerate = [(True, False), (False, True), (False, False), (True, True)][seed % 4]
+    rule = ("hybrid_residual", "residual", "norm_residual", "ratio_residual")[(seed // 4) % 4]
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=50, tolerance=1e-7, evaluate_objective=bool(seed % 2),
+                window=int(rng.randint(1, 12)), restart=bool((seed // 2) % 2), stop_rule=getattr(stopping, rule))
+    mu = 0.05
+    reg, P = {"shrink": (fa.Shrink(mu), pr.sparse_least_squares_from(A, b, mu)), "nonneg": (fa.NonNeg(), pr.nn_least_squares_from(A, b))}[kind]
+    ls = fa.LeastSquares(b)
+    np.random.seed(seed)
+    got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", device_iters=int(rng.randint(1, 40)), **opts)
+    assert got.device_steps == got.iteration_count, "the device loop did not take this solve"
+    oracle_opts = dict(opts, stop_rule=getattr(fo, rule))
+    np.random.seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(P.A, P.At, P.f, P.gradf, P.g, P.proxg, x0, **oracle_opts)
+    # Histories are compared while the solve is still moving: these tiny underdetermined instances reach machine precision within 20-30
+    # iterations (residual 1e-8 of its start), after which step sizes and residuals are rounding noise in the oracle, in the per-iteration
+    # path and here alike (seed 11: all three part at iteration 25).  Counts, the solution and the untruncated shapes are compared always.
+    k = want.iteration_count
+    assert got.iteration_count == k and got.backtracks == want.backtracks
+    small = np.nonzero(want.residuals[:k] < 1e-6 * want.residuals[0])[0]
+    kk = int(small[0]) if small.size else k
+    for f, r in (("residuals", 1e-5), ("norm_residuals", 1e-5), ("stepsizes", 2e-4)):
+        np.testing.assert_allclose(getattr(got, f)[:kk], getattr(want, f)[:kk], rtol=r, atol=1e-14, err_msg=f)
+    if want.objectives is not None:
+        np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-5, atol=1e-14)
+    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-8)
+    assert got.residuals.shape == want.residuals.shape and got.times.shape == want.times.shape
