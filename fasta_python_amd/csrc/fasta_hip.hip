@@ -94,6 +94,8 @@ static int create_body(fh_ctx* c, int device, hipStream_t shared_stream = nullpt
   { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); c->ncu = prop.multiProcessorCount; }
   HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMalloc((void**)&c->gridbar, GB_WORDS * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
   HIP_TRY(hipMalloc((void**)&c->dscal, (FH_NSCALARS + 16) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->dscal, 0, (FH_NSCALARS + 16) * sizeof(double), c->stream));
   HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocMapped));
@@ -212,6 +214,7 @@ extern "C" int fh_destroy(fh_ctx* c) {
   free_operator(c);
   if (c->run_st_host) (void)hipHostFree(c->run_st_host);
   if (c->run_hist) (void)hipHostFree(c->run_hist);
+  if (c->gridbar) (void)hipFree(c->gridbar);
   if (c->lvl_rec) (void)hipFree(c->lvl_rec);
   if (c->lvl_cnt) (void)hipFree(c->lvl_cnt);
   if (c->counters) (void)hipFree(c->counters);
@@ -636,7 +639,8 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   p.slots = c->slotbuf;
   if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
+  p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
@@ -1037,8 +1041,9 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   const size_t gpart_elems = (size_t)grid * p.nv2 * 2;
   FH_TRY(ensure_ws(c, (gpart_elems + (size_t)2 * grid * 16) * sizeof(double)));
   p.gpart = c->ws; p.red = p.gpart + gpart_elems;
+  HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_RUN_BAR, 0, 2 * sizeof(unsigned), c->stream));
-  p.bar = c->counters + CNT_RUN_BAR; p.err = c->counters + CNT_RUN_BAR + 1;
+  p.bar = c->gridbar; p.err = c->counters + CNT_RUN_BAR + 1;
   t_begin(c, FH_K_FUSED);
   e->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FUSED);

@@ -266,6 +266,47 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, v
   return *flag != 0u;
 }
 
+// ---- two-level grid barrier (round 5) ------------------------------------------------------------------------------------------------------
+// A generation barrier for co-resident workgroups.  G atomic adds on ONE address cost 3.6 us at G = 256 and 8.0 us at G = 512 (same-address
+// atomics serialise at the memory side); with the arrivals spread over GB_GROUPS counters on separate 128-byte lines -- workgroup b arrives at
+// counter b % GB_GROUPS, the last arriver of a group at the top counter, the last of those publishes the generation in a release word that
+// everybody polls with plain write-through-coherent loads -- the same barrier costs 1.5 / 1.6 us (scripts/bench_mem/gridbar.hip,
+// profiles/r05_gridbar.txt; polling the release word with SCALAR glc loads instead: 17-45 us, hundreds of pollers on one line).
+// All counters only grow: `gen` = 1, 2, 3, ... counts the barriers of the launch; the host zeroes the GB_WORDS words before the launch.
+// Bounded: after FT_SPIN_TICKS-like `budget` ticks of the 100 MHz clock the caller's `err` word is set and false is returned (every
+// workgroup then times out by itself, so the grid drains).
+#define GB_GROUPS 32
+#define GB_WORDS (GB_GROUPS * 32 + 64)
+__device__ __forceinline__ bool grid_barrier2(unsigned* base, unsigned gen, unsigned* err, unsigned long long budget, volatile unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned G = gridDim.x, g = blockIdx.x % GB_GROUPS;
+    const unsigned ngroups = G < GB_GROUPS ? G : GB_GROUPS;
+    const unsigned gsize = (G - g + GB_GROUPS - 1u) / GB_GROUPS;                  // workgroups that arrive at my group's counter
+    unsigned* top = base + GB_GROUPS * 32;
+    unsigned* rel = top + 32;
+    const unsigned old = __hip_atomic_fetch_add(base + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == gen * gsize) {                                                  // last of my group in this generation
+      const unsigned o2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o2 + 1u == gen * ngroups) __hip_atomic_store(rel, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned ok = 1u;
+    while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0u;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *flag = ok;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
 // K doubles per workgroup, all held by thread 0 (the usual case after block_reduce)
 template <int K>
 __device__ __forceinline__ bool publish_partials(double* slot, const double (&v)[K], unsigned* counter, unsigned total,

@@ -441,7 +441,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     c->slots_sig = 0;
   }
   p.g1 = io.g1;
-  p.bar = c->counters + CNT_FUSED_BAR; p.err = c->counters + CNT_FUSED_ERR;
+  p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);
@@ -453,6 +453,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
       // that timed out in another shape must not leave them armed for it)
       if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
       HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
+      HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
       c->slots_sig = sig;
       c->slots_parity = 0;
     }

@@ -35,7 +35,8 @@ struct SetupP {
   double* slots;               // [mp][NR][max(TEAM, 8)], every double the sentinel on entry
   double* gpart;               // [nteams][FS_NR][nv2] double pairs
   double* red;                 // [grid][8]
-  unsigned* bar;               // [0] grid barrier arrivals, [1] final arrivals (zero on entry; the finaliser zeroes them again)
+  unsigned* bar;               // [1] final arrivals (zero on entry; the finaliser zeroes it again)
+  unsigned* gbar;              // GB_WORDS words of the two-level grid barrier (fh_device.h:grid_barrier2), zero on entry, zeroed again at the end
   unsigned* err;
   int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls (as FusedP.variant)
   double* out;                 // scalar block: [S_FSQ] loss sum at x0, [S_DX2] ||x1 - x2||^2, [S_DG2] ||grad1 - grad2||^2, [15] timeout
@@ -376,20 +377,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
   }
 
   // ---------------- bounded grid barrier (one workgroup per CU: all co-resident) ------------------------------------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > FT_SPIN_TICKS) {
-        __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
+  (void)grid_barrier2(p.gbar, 1u, p.err, FT_SPIN_TICKS, s_flag);
 
   // ---------------- every workgroup finalises its share of the columns: team-ordered sums (k_fused_dense's split), ||grad1 - grad2||^2
   double dg2 = 0.0;
@@ -454,4 +442,5 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid < GB_GROUPS + 2) __hip_atomic_store(p.gbar + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // group counters, top counter, release word
 }
