@@ -94,8 +94,8 @@ static int create_body(fh_ctx* c, int device, hipStream_t shared_stream = nullpt
   { hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device)); c->ncu = prop.multiProcessorCount; }
   HIP_TRY(hipMalloc((void**)&c->counters, kCounterWords * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(c->counters, 0, kCounterWords * sizeof(unsigned), c->stream));
-  HIP_TRY(hipMalloc((void**)&c->gridbar, GB_WORDS * sizeof(unsigned)));
-  HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMalloc((void**)&c->gridbar, 3 * GB_WORDS * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(c->gridbar, 0, 3 * GB_WORDS * sizeof(unsigned), c->stream));
   HIP_TRY(hipMalloc((void**)&c->dscal, (FH_NSCALARS + 16) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->dscal, 0, (FH_NSCALARS + 16) * sizeof(double), c->stream));
   HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocMapped));
@@ -639,7 +639,7 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   p.slots = c->slotbuf;
   if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-  HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMemsetAsync(c->gridbar, 0, 2 * GB_WORDS * sizeof(unsigned), c->stream));
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);

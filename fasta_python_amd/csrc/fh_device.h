@@ -307,6 +307,28 @@ __device__ __forceinline__ bool grid_barrier2(unsigned* base, unsigned gen, unsi
   return *flag != 0u;
 }
 
+// "Who is last?" over the same two levels (a second block of GB_WORDS words): true in EVERY thread of the last-arriving workgroup of the grid.
+// One-shot (the counters are zero on entry; the caller's last workgroup zeroes them again).  The flat form -- arrive_last on one counter --
+// makes the last arriver queue behind up to G - 1 same-address atomics when the workgroups finish together, as they do after a grid barrier.
+__device__ __forceinline__ bool arrive_last2(unsigned* base, volatile unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned G = gridDim.x, g = blockIdx.x % GB_GROUPS;
+    const unsigned ngroups = G < GB_GROUPS ? G : GB_GROUPS;
+    const unsigned gsize = (G - g + GB_GROUPS - 1u) / GB_GROUPS;
+    unsigned last = 0u;
+    const unsigned old = __hip_atomic_fetch_add(base + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == gsize) {
+      const unsigned o2 = __hip_atomic_fetch_add(base + GB_GROUPS * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (o2 + 1u == ngroups) ? 1u : 0u;
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
 // K doubles per workgroup, all held by thread 0 (the usual case after block_reduce)
 template <int K>
 __device__ __forceinline__ bool publish_partials(double* slot, const double (&v)[K], unsigned* counter, unsigned total,

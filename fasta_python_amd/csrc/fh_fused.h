@@ -92,7 +92,7 @@ struct FusedP {
   double* g1;
   double* red;           // [grid][16] reduction partials
   unsigned* bar;         // [1] final arrivals   (zero on entry; the finaliser zeroes it again)
-  unsigned* gbar;        // GB_WORDS words of the two-level grid barrier (fh_device.h:grid_barrier2); zero on entry, zeroed again by the finaliser
+  unsigned* gbar;        // 2 x GB_WORDS words: the two-level grid barrier and the two-level final arrival (fh_device.h:grid_barrier2 / arrive_last2); zero on entry, zeroed again by the finaliser
   unsigned* err;         // set to 1 on a spin timeout
   int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep between polls, 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
   double* out;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
     printf("fused phases (block 0, us): prologue %.1f | rows %.1f | loss+publish %.1f | grid barrier %.1f | finalise %.1f\n",
            (phase[1] - phase[0]) * 0.01, (phase[2] - phase[1]) * 0.01, (phase[3] - phase[2]) * 0.01, (phase[4] - phase[3]) * 0.01, (phase[5] - phase[4]) * 0.01);
 #endif
-  if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
+  if (!arrive_last2(p.gbar + GB_WORDS, s_flag)) return;
   double w[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
 #pragma unroll
@@ -653,5 +653,8 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
       __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid < GB_GROUPS + 2) __hip_atomic_store(p.gbar + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // group counters, top counter, release word
+  if (tid < GB_GROUPS + 2) {      // both blocks: group counters, top counter, release word
+    __hip_atomic_store(p.gbar + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.gbar + GB_WORDS + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }

@@ -207,7 +207,7 @@ struct fh_ctx {
   // fh_run (csrc/fh_run.h): the host-mapped block the launch writes its final solver state to, and the host-mapped history block
   void* run_st_host = nullptr; void* run_st_host_dev = nullptr;
   double* run_hist = nullptr; double* run_hist_dev = nullptr; size_t run_hist_steps = 0;
-  unsigned* gridbar = nullptr;       // GB_WORDS words of the two-level grid barrier (fh_device.h:grid_barrier2) of the one-pass, set-up and persistent-loop kernels; zero between launches
+  unsigned* gridbar = nullptr;       // 3 x GB_WORDS words: two-level grid barrier, two-level final arrival of the dense one-pass / set-up / persistent-loop kernels, final arrival of the stencil sweep (fh_device.h); zero between launches
   double* lvl_rec = nullptr;         // multi-workgroup level search: per-pass records and counters (allocated on first use, counters kept zero)
   unsigned* lvl_cnt = nullptr;
   double* selftest_buf = nullptr;    // fh_comm_selftest's scratch (freed before it returns)

@@ -453,7 +453,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
       // that timed out in another shape must not leave them armed for it)
       if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, 2 * slots_elems * 2, c->stream));
       HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
-      HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
+      HIP_TRY(hipMemsetAsync(c->gridbar, 0, 2 * GB_WORDS * sizeof(unsigned), c->stream));
       c->slots_sig = sig;
       c->slots_parity = 0;
     }
@@ -691,6 +691,7 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
 #endif
   FH_TRY(ensure_ws(c, (size_t)grid * 16 * sizeof(double)));
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
+  p.arrive = c->gridbar + 2 * GB_WORDS;
   t_begin(c, FH_K_FUSED);
   // tunables -> template parameters.  Non-temporal LOADS lose 12 % here (the halo columns and rows are re-read by the neighbouring
   // waves and workgroups through L2), so this sweep only distinguishes non-temporal (default) and plain STORES (FH_TUNE_TV_NT = 3).

@@ -36,7 +36,7 @@ struct SetupP {
   double* gpart;               // [nteams][FS_NR][nv2] double pairs
   double* red;                 // [grid][8]
   unsigned* bar;               // [1] final arrivals (zero on entry; the finaliser zeroes it again)
-  unsigned* gbar;              // GB_WORDS words of the two-level grid barrier (fh_device.h:grid_barrier2), zero on entry, zeroed again at the end
+  unsigned* gbar;              // 2 x GB_WORDS words: the two-level grid barrier and final arrival (fh_device.h:grid_barrier2 / arrive_last2), zero on entry, zeroed again at the end
   unsigned* err;
   int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls (as FusedP.variant)
   double* out;                 // scalar block: [S_FSQ] loss sum at x0, [S_DX2] ||x1 - x2||^2, [S_DG2] ||grad1 - grad2||^2, [15] timeout
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     fs_block_reduce<1, NW>(w, s_scr);
     if (tid == 0) store_partial(p.red + (uint64_t)blockIdx.x * 8 + 2, w[0]);
   }
-  if (!arrive_last(p.bar + 1, gridDim.x, s_flag)) return;
+  if (!arrive_last2(p.gbar + GB_WORDS, s_flag)) return;
   double w[3] = {0, 0, 0};
   if (tid < FH_WG) {
     for (uint32_t i = tid; i < gridDim.x; i += FH_WG) {
@@ -442,5 +442,8 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid < GB_GROUPS + 2) __hip_atomic_store(p.gbar + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // group counters, top counter, release word
+  if (tid < GB_GROUPS + 2) {      // both blocks: group counters, top counter, release word
+    __hip_atomic_store(p.gbar + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.gbar + GB_WORDS + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }

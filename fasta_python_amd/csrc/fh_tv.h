@@ -940,6 +940,7 @@ struct TvZP {
   int xcd_order;                         // 1 = logical workgroup ids dealt out XCD by XCD (tv_xcd_order)
   uint32_t nchunks;                      // strip_groups * row bands; a smaller grid walks the chunk ids with stride gridDim.x
   double* red; unsigned* counter; double* out;
+  unsigned* arrive;                      // GB_WORDS words of the two-level final arrival (fh_device.h:arrive_last2): ~1260 workgroups finish together here
 };
 
 // NT: bit 0 = non-temporal loads, bit 1 = non-temporal stores.  The host only instantiates NT = 2 (non-temporal stores, the default)
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       store_partial(slot + 15, fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7])));
     }
   }
-  if (!arrive_last(p.counter, gridDim.x, s_flag)) return;
+  if (!arrive_last2(p.arrive, s_flag)) return;
   double t[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) t[k] = 0.0;
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       p.out[S_FSQ_ADJ] = plain ? a[0] : bq[5];
       p.out[S_ALPHA] = 0.0;
       p.out[15] = 0.0;
-      __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (tid < GB_GROUPS + 1) __hip_atomic_store(p.arrive + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave the arrival counters zero for the next launch
 }
