@@ -198,15 +198,17 @@ class FBSolver:
         # How the two halves of an iteration reach the device:
         #   "always"      one-pass kernel for every launch of the loop, backtracking retries included: where it costs no more
         #                 than K-fwd alone -- the stencil, and the dense operator from n = 16384 (kind 1: 65536^2 5.0 vs 4.9 ms)
-        #   "speculative" one-pass kernel on a dense operator below that size (kind 3, only with fused=True): a rejected step
-        #                 wastes the A^T half, so back off for a few iterations after a backtrack
-        #   "pair"        K-fwd and K-adj enqueued back to back under one synchronisation (fused="auto", short launches, no
-        #                 acceleration): the host round trip is what costs there; speculative in the same way
+        #   "speculative" one-pass kernel on a dense operator below that size (kind 3): a rejected step wastes the A^T half, so
+        #                 back off for a few iterations after a backtrack.  Since round 5 (two-level grid barrier and final arrival:
+        #                 a one-pass launch of a small matrix costs 18-27 us) this is what fused="auto" takes at EVERY size down to
+        #                 64 x 128 -- 2048^2: 21 300 it/s against 10 400 for the pair below (profiles/r05_crossover.txt)
+        #   "pair"        K-fwd and K-adj enqueued back to back under one synchronisation (operators without a one-pass kernel, or whose
+        #                 co-residency probe said no; no acceleration): the host round trip is what costs there; speculative in the same way
         #   None          fh_fwd, decide, fh_adj
         self.mode = None
         if kind in (1, 2):
             self.mode = "always"
-        elif kind == 3 and self.fused_opt is True:
+        elif kind == 3 and self.fused_opt in (True, "auto"):
             self.mode = "speculative"
         elif (self.fused_opt == "auto" and kind in (0, 3) and not self.accelerate and hasattr(c, "fwd_adj")
               and getattr(self.A, "shape", None) is not None and len(self.A.shape) == 2
