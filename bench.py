@@ -644,6 +644,13 @@ def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096), (6000,
     return out
 
 
+def settle_after_free(gib):
+    """The driver clears freed device memory in the background: for ~30 ms per GiB freed a read-only stream over OTHER, resident memory runs
+    3 % slow (profiles/r05_free_aftermath.txt: 7.16 -> 6.95 TB/s for 2.9 s after 96 GiB were freed).  A sub-result timed right behind a
+    large hipFree would carry that; wait it out (about 10 s over the whole default run)."""
+    time.sleep(0.2 + 0.035 * gib)
+
+
 def sub_result(r, workload):
     d = r["per_kernel"].get(r["dominant"], {}) if r["dominant"] else {}
     return {"workload": workload, "value": r["value"], "unit": "iterations/s", "ms_per_step": r["ms_per_step"],
@@ -911,6 +918,7 @@ def main(argv=None):
                 r = run_dense(args, grp, A32, m_total, n, "lasso", fused, args.steps, args.warmup)
             finally:
                 A32.close()
+                settle_after_free(m_total * n * 4 / 2 ** 30)
             s32 = sub_result(r, f"LASSO {m_total}x{n}, A stored float32 (opt-in; vectors, accumulation and scalars float64)")
             s32["dtype"] = "f32-storage"
             s32["tolerance"] = ("iterates equal the reference's run on A.astype(float32) to the float64 path's tolerances; against the "
@@ -928,6 +936,7 @@ def main(argv=None):
                     extra["lasso_wide_131072"] = s
                 finally:
                     Aw.close()
+                    settle_after_free(32)
             # TV: warmed up INTO the backtracking regime (the adaptive run starts backtracking after ~40 iterations and then does so
             # every second or third one) and timed over 100 iterations, whatever --steps / --warmup say
             for key, acc in (("tv", False), ("tv_accelerated", True)):
@@ -948,6 +957,7 @@ def main(argv=None):
             # blocks, 8 n-side epilogues, one synchronisation) costs next to the single launch of the headline
             if (m_total, n) == (65536, 65536) and "inproc" not in args.skip_extra.split(","):
                 A.close()
+                settle_after_free(32)
                 A8 = fa.ShardedDenseMatrixMap.synthetic(m_total, n, seed=0, scale=synthetic.lasso_scale(m_total, n),
                                                         devices=[grp.local_rank] * 8, tuning=tuning)
                 try:
@@ -958,6 +968,7 @@ def main(argv=None):
                     extra["inproc_8_row_blocks"] = s
                 finally:
                     A8.close()
+                    settle_after_free(32)
                 # BASELINE config 5's matrix ITSELF (262144 x 65536 float64 = 128 GiB: it fits one MI355X) as its 8 per-GPU shards of
                 # 32768 x 65536, all on this GPU one after the other.  NOT a scaling number: it is the full config-5 problem solved
                 # through the row-sharded code path on the hardware a one-GPU box has; an 8-GPU run does each block on its own device.
@@ -972,6 +983,7 @@ def main(argv=None):
                     extra["config5_matrix_on_one_gpu"] = s
                 finally:
                     A5.close()
+                    settle_after_free(128)
                 A = shard(m_total)                     # (the CPU baseline below pulls the matrix back from HBM)
     if extra:
         result["extra"] = extra
