@@ -904,6 +904,7 @@ def main(argv=None):
         if args.gpus > 1 or grp.force:                 # (FASTA_BENCH_FORCE_DIST=1 rehearses this branch with one rank)
             # BASELINE config 5's per-GPU shape: 32768 rows per rank (N = 8 gives the 262144 x 65536 matrix itself)
             A.close()
+            settle_after_free(m_total // grp.world * n * 8 / 2 ** 30)
             A = shard(32768 * args.gpus)
             ctx = A.ctx
             r = run_dense(args, grp, A, 32768 * args.gpus, n, "lasso", fused, args.steps, args.warmup)
