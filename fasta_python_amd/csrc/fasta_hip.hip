@@ -226,6 +226,14 @@ extern "C" int fh_destroy(fh_ctx* c) {
   return 0;
 }
 
+// process-wide: wait (or not) with a large matrix allocation until this process's earlier large frees have been cleared by the driver
+extern "C" int fh_alloc_settle(int enable) { g_settle_on.store(enable ? 1 : 0); return 0; }
+extern "C" int fh_alloc_settle_waited(double* seconds) {
+  if (!seconds) return fail(FH_E_ARG, "null argument");
+  *seconds = (double)g_settle_waited_ns.load() * 1e-9;
+  return 0;
+}
+
 extern "C" int fh_sync(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
   if (c->shards.empty()) FH_TRY(use_device(c));
@@ -325,7 +333,9 @@ static int setup_dense(fh_ctx* c, uint64_t m, uint64_t n) {
   c->mp = round_up(m, 16);
   c->ld = round_up(n, c->f32 ? 32 : 16) + (uint64_t)c->ld_pad;      // rows stay 128-byte aligned in either storage
   c->nv = c->ld; c->mv = c->mp;
-  HIP_TRY(hipMalloc((void**)&c->A, c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double))));
+  const size_t a_bytes = (size_t)c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double));
+  settle_before_large_alloc(a_bytes);             // (a large free of this process may still be being cleared: fh_host_ctx.h)
+  HIP_TRY(hipMalloc((void**)&c->A, a_bytes));
   FH_TRY(alloc_vectors(c));
   c->op = OP_DENSE;
   return 0;

@@ -2,6 +2,9 @@
 // or a shell over one shard per device), buffer management, HIP-event timing, the scalar block's way back to the host and the
 // sums over row blocks.  Included by fasta_hip.hip only (one translation unit); the C ABI itself is in fasta_hip.hip.
 #pragma once
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <chrono>
 
 // ------------------------------------------------------------------------------------------------
@@ -238,9 +241,36 @@ static int use_device(fh_ctx* c) {
   return 0;
 }
 
+// ---- large frees and the allocations behind them -------------------------------------------------------------------------------------
+// The driver clears freed device memory in the background, ~30 ms per GiB on MI355X: meanwhile a read-only stream over OTHER memory runs
+// 3 % slow, and -- what matters here -- a large allocation made while the clearing is still going on can come out 6-8 % slow for its whole
+// lifetime (profiles/r05_free_aftermath.txt: the "wide-row / config-5 outlier" of the round-3..5 bench lines).  The library therefore
+// remembers, process-wide, when its own large frees will have been cleared and lets the next large matrix allocation wait for that moment
+// (fh_alloc_settle(0) switches the wait off; fh_alloc_settle_waited reports what it has cost so far).
+static std::atomic<long long> g_clear_until_ns{0};       // steady clock
+static std::atomic<long long> g_settle_waited_ns{0};
+static std::atomic<int> g_settle_on{1};
+static const size_t kSettleMinBytes = (size_t)1 << 30;
+static const double kClearNsPerByte = 35.0e6 / (double)((size_t)1 << 30);     // 35 ms per GiB (measured: 2.9 s for 96 GiB)
+static long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void note_large_free(size_t bytes) {
+  if (bytes < kSettleMinBytes) return;
+  const long long now = steady_ns(), add = (long long)(kClearNsPerByte * (double)bytes);
+  long long cur = g_clear_until_ns.load();
+  while (!g_clear_until_ns.compare_exchange_weak(cur, std::max(cur, now) + add)) { }
+}
+static void settle_before_large_alloc(size_t bytes) {
+  if (!g_settle_on.load() || bytes < kSettleMinBytes) return;
+  const long long wait = g_clear_until_ns.load() - steady_ns();
+  if (wait <= 0) return;
+  std::this_thread::sleep_for(std::chrono::nanoseconds(wait));
+  g_settle_waited_ns.fetch_add(wait);
+}
+
 static void free_operator(fh_ctx* c) {
   for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); free_operator(s); }
   auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  if (c->A && c->op == OP_DENSE) note_large_free((size_t)c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double)));
   fr(c->A);
   for (int i = 0; i < 2; ++i) { fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
   for (int i = 0; i < 3; ++i) fr(c->X[i]);

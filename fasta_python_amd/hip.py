@@ -101,6 +101,8 @@ SIGNATURES = {
     "fh_comm_destroy": (_i32, [_ctx]),
     "fh_comm_library": (C.c_char_p, []),
     "fh_comm_version": (_i32, [C.POINTER(_i32)]),
+    "fh_alloc_settle": (_i32, [_i32]),
+    "fh_alloc_settle_waited": (_i32, [C.POINTER(_dbl)]),
     "fh_comm_selftest": (_i32, [_ctx, _u64, _pd, C.POINTER(_i32)]),
     "fh_cu_count": (_i32, [_ctx, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_timing_enable": (_i32, [_ctx, _i32]),
@@ -184,6 +186,21 @@ def comm_version():
     v = _i32(-1)
     _check(lib, lib.fh_comm_version(C.byref(v)))
     return int(v.value)
+
+
+def alloc_settle(enable=True):
+    """Process-wide: wait with a large (>= 1 GiB) matrix allocation until this process's earlier large frees have been cleared by the driver
+    (default on; see include/fasta_hip.h and profiles/r05_free_aftermath.txt)."""
+    lib = load_library()
+    _check(lib, lib.fh_alloc_settle(1 if enable else 0))
+
+
+def alloc_settle_waited():
+    """Seconds the library has spent in that wait so far (process-wide)."""
+    lib = load_library()
+    v = _dbl(0.0)
+    _check(lib, lib.fh_alloc_settle_waited(C.byref(v)))
+    return float(v.value)
 
 
 def comm_unique_id():

@@ -284,6 +284,14 @@ int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
 /* ranks of the attached communicator as RCCL reports them (ncclCommCount); 1 without a communicator */
 int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
+/* Large frees and the allocations behind them (process-wide).  The driver clears freed device memory in the background (~30 ms per GiB on
+ * MI355X); a large allocation made meanwhile can come out 6-8 % slow for its whole lifetime (profiles/r05_free_aftermath.txt).  By default
+ * fh_set_matrix / fh_generate_matrix wait, before allocating a matrix of >= 1 GiB, until the matrices (>= 1 GiB) this process has freed through
+ * the library have presumably been cleared (35 ms per GiB behind the free).  fh_alloc_settle(0) switches that wait off, fh_alloc_settle(1) on;
+ * fh_alloc_settle_waited returns the seconds spent waiting so far.                                                                          */
+int fh_alloc_settle(int enable);
+int fh_alloc_settle_waited(double* seconds);
+
 /* RCCL's version code as ncclGetVersion reports it; -1 when no library is loaded yet or it does not export the symbol           */
 int fh_comm_version(int* version);
 /* The context's exchange (the rank's all-reduce, or a multi-device context's grouped all-reduce / in-library sum) on a known

@@ -411,3 +411,33 @@ def test_fwd_adj_under_one_sync_equals_fwd_then_adj(m, n):
         np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-8, atol=1e-14)
     finally:
         op.close()
+
+
+def test_a_large_allocation_waits_for_the_clearing_of_a_large_free():
+    """fh_alloc_settle (process-wide, default on): a matrix of >= 1 GiB allocated right behind the free of one waits ~35 ms per GiB freed -- the driver
+    clears freed memory in the background and an allocation made meanwhile can come out 6-8 % slow for its lifetime (profiles/r05_free_aftermath.txt);
+    switched off, it does not wait; small matrices never do."""
+    import time
+    time.sleep(0.3)                                       # (frees of earlier tests)
+    gib2 = (16384, 16384)                                 # 2 GiB
+    def cycle():
+        a = fa.DenseMatrixMap.synthetic(*gib2, 0, 1e-3); a.close()
+        w0, t0 = hip.alloc_settle_waited(), time.perf_counter()
+        b = fa.DenseMatrixMap.synthetic(*gib2, 0, 1e-3)
+        waited, wall = hip.alloc_settle_waited() - w0, time.perf_counter() - t0
+        b.close()
+        return waited, wall
+    waited, wall = cycle()
+    assert 0.02 < waited < 0.2 and wall >= waited, (waited, wall)          # 2 GiB freed -> ~70 ms, minus what the free itself took
+    time.sleep(0.3)
+    hip.alloc_settle(False)
+    try:
+        waited, _ = cycle()
+        assert waited == 0.0
+    finally:
+        hip.alloc_settle(True)
+    time.sleep(0.3)
+    a = fa.DenseMatrixMap.synthetic(4096, 4096, 0, 1e-3); a.close()          # 128 MiB: below the threshold
+    w0 = hip.alloc_settle_waited()
+    b = fa.DenseMatrixMap.synthetic(4096, 4096, 0, 1e-3); b.close()
+    assert hip.alloc_settle_waited() == w0
