@@ -618,7 +618,10 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   const FusedShape sh = fused_shape(c);
   if (!sh.ppt || sh.xlds) return 0;
   const SetupEntry* e = nullptr;
-  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) { e = &k; break; }
+  // full 8-piece shapes of 8 / 16 members: 512-thread workgroups (fh_setup_instances.inc); FH_TUNE_FUSED_VARIANT bit 16 keeps the 256-thread form (A/B)
+  const int want_threads = (sh.ppt == 8 && sh.team >= 8 && sh.team <= 16 && !(c->fused_variant & 16)) ? 512 : 256;
+  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe) && k.threads == want_threads) { e = &k; break; }
+  if (!e && want_threads == 512) for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) { e = &k; break; }
   if (!e || !co_resident(c)) return 0;
   SetupP p;
   p.A = c->A; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;

@@ -13,7 +13,8 @@
 //     right-hand side (scalar loads, bounded) and broadcast its gradient factor -- a trip is no longer than k_fused_dense's;
 //   * every right-hand side is summed in exactly the order k_fused_dense sums it (pieces in lane order, DPP wave sum, waves
 //     0..3, members 0..TEAM-1, teams 0..nteams-1 with the same slice split in the finaliser), so g0 / z / f come out BIT-IDENTICAL
-//     to fh_init's one-pass launch, and L agrees with the three-pass value to ~1e-15 relative -- tests/test_gpu_setup.py;
+//     to fh_init's one-pass launch in the 256-thread shapes (the two 512-thread shapes below: equal to summation-order rounding), and L
+//     agrees with the three-pass value to ~1e-15 relative -- tests/test_gpu_setup.py;
 //   * the finaliser also forms ||A^T A d||^2 and (team 0's prologue) ||x1 - x2||^2: the two norms of :110 come back with the scalar
 //     block, no further launch.
 // Shapes: float64 storage, PPT <= 8 (n <= 65536): NR x PPT x 4 KiB of LDS for the x slices, NR x PPT x 4 registers for the gradient
@@ -75,7 +76,9 @@ __device__ __forceinline__ void fs_block_reduce(double (&v)[K], double* scr) {
 // NT: threads per workgroup, 256 or 512.  With 512 threads a lane holds ceil(MPP / 2) pieces: two waves per SIMD of at most 256
 // registers each, where 256 lanes x 8 pieces x (3 gradient slices + 4 row buffers) does not fit one wave's registers without spilling
 // into the loops.  With 256 threads every right-hand side is summed exactly as k_fused_dense sums it (bit-identical results); with
-// 512 the lane -> piece map differs and the results agree to summation-order rounding.
+// 512 the lane -> piece map differs and the results agree to summation-order rounding.  SHIPPED with 512 threads: the full 8-piece shapes of 8 and
+// 16 members (two right-hand sides double the issue slots per byte; the second wave per SIMD hides the first one's LDS reads, multiply-add chains
+// and polls: 65536^2 5.13-5.28 -> 4.97-4.99 ms, at the speed of a step launch); everything else runs 256 threads.
 // NR = 3: right-hand sides x1, x2, x0, each with the residual r = z - b (the reference's three passes verbatim).
 // NR = 2: the two probes enter only through their DIFFERENCE -- grad(x1) - grad(x2) = A^T A (x1 - x2) for the least-squares loss -- so
 //         right-hand side 0 is d = x1 - x2 with the homogeneous residual r = z, right-hand side 1 is x0 with r = z - b: one dot product,
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) buf[k] = load_stream<1>(src + pc[k]);
   };
-  constexpr int NB = PPT >= 7 ? (NR == 2 && PIPE >= 2 ? 5 : 4) : (PPT >= 5 ? 5 : 6);      // row buffers: what fits next to the gradient slices
+  constexpr int NB = NT == 512 ? 4 : (PPT >= 7 ? (NR == 2 && PIPE >= 2 ? 5 : 4) : (PPT >= 5 ? 5 : 6));      // row buffers: what fits next to the gradient slices (512 threads: 256 registers per lane)
   PT B[NB][PPT];
 
   // ---------------- n-side: the three x slices into LDS (each lane reads back only its own entries); ||x1 - x2||^2 by team 0
