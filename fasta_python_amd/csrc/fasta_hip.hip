@@ -653,7 +653,7 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   if (sh.team > 1) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)c->slotbuf, (int)FT_SENTINEL_HI, slots_elems * 2, c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->gridbar, 0, 2 * GB_WORDS * sizeof(unsigned), c->stream));
-  p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
+  p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);

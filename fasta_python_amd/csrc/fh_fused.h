@@ -91,6 +91,7 @@ struct FusedP {
   double* gpart;         // [nteams][ld]
   double* g1;
   double* red;           // [grid][16] reduction partials
+  unsigned* bar;         // [1] final arrivals   (zero on entry; the finaliser zeroes it again)
   unsigned* gbar;        // 2 x GB_WORDS words: the two-level grid barrier and the two-level final arrival (fh_device.h:grid_barrier2 / arrive_last2); zero on entry, zeroed again by the finaliser
   unsigned* err;         // set to 1 on a spin timeout
   int variant;           // bits: 2 = team members 32 blocks apart (one XCD), 4 = no s_sleep between polls, 8 = n=65536 as 8 members x 16 pieces, 32 = rows dealt cyclically to the teams, 64 = fault injection (tests)
@@ -646,7 +647,9 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
       const double timed_out = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
       p.out[15] = timed_out;
       if (p.pack) { p.pack[0] = a[0]; p.pack[1] = timed_out; p.pack[2] = p.accel ? a[7] : a[0]; }
-      // leave the error word zero for the next launch (the barrier and arrival counters: all threads, below)
+      // leave the counters zero for the next launch (every workgroup is past the grid barrier and has taken its final ticket)
+      __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -441,7 +441,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     c->slots_sig = 0;
   }
   p.g1 = io.g1;
-  p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
+  p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
   p.out = scalar_out(c);
   t_begin(c, FH_K_FUSED);

@@ -36,6 +36,7 @@ struct SetupP {
   double* slots;               // [mp][NR][max(TEAM, 8)], every double the sentinel on entry
   double* gpart;               // [nteams][FS_NR][nv2] double pairs
   double* red;                 // [grid][8]
+  unsigned* bar;               // [1] final arrivals (zero on entry; the finaliser zeroes it again)
   unsigned* gbar;              // 2 x GB_WORDS words: the two-level grid barrier and final arrival (fh_device.h:grid_barrier2 / arrive_last2), zero on entry, zeroed again at the end
   unsigned* err;
   int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls (as FusedP.variant)
@@ -440,6 +441,8 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     for (int k = 0; k < 16; ++k) p.out[k] = 0.0;
     p.out[S_FSQ] = w[0]; p.out[S_DX2] = w[1]; p.out[S_DG2] = w[2];
     p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;
+    __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid < GB_GROUPS + 2) {      // both blocks: group counters, top counter, release word
