@@ -4,7 +4,7 @@ import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "fasta_python_amd", "csrc")
 src, pat, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
-out = os.path.join(tempfile.gettempdir(), "loop_spills.s")
+out = os.path.join(tempfile.gettempdir(), f"loop_spills_{os.getpid()}.s")
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out,
                 os.path.join(csrc, src)] + flags, check=True, cwd=csrc, stderr=subprocess.DEVNULL)
 L = open(out).read().split("\n")
@@ -25,3 +25,4 @@ for st in starts:
             if n:
                 rows.append(f"depth {d}: {n}")
     print(f"{L[st][:60]:60s} scratch ops {len(sc):4d}; inside loops: {', '.join(rows) if rows else 'none'}")
+os.remove(out)
