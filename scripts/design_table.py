@@ -34,7 +34,7 @@ Medians of repeated fresh solves as in round 4. Leases differ by 1–3 % (headli
 | C4 FISTA | {f(e['tv_accelerated']['value'],0)} | `k_tv_onepass<0,1,4,2,3,0>` {f(e['tv_accelerated']['avg_launch_ms'],4)} ms (rocprofv3 {f(roc('void k_tv_onepass<0, 1, 4, 2, 3, 0>')[1],4)}) | {f(e['tv_accelerated']['achieved_GB/s'],0)} GB/s on 56·P (PMC: {f(traffic('void k_tv_onepass<0, 1, 4, 2, 3, 0>'),3)} GB) | {f(e['tv_accelerated']['frac'],3)} | 1259 |
 | LASSO 32 768 × 131 072 | {f(e['lasso_wide_131072']['value'])} | `k_fused_dense<16,1,1,16,1,3,0>` {f(e['lasso_wide_131072']['avg_launch_ms'],3)} ms (rocprofv3 {f(roc('void k_fused_dense<16, 1, 1, 16, 1, 3, 0>')[1],3)}) | {f(e['lasso_wide_131072']['achieved_GB/s'],0)} GB/s | {f(e['lasso_wide_131072']['frac'],3)} | 204–208 (outlier 5.28 ms: explained below) |
 | float32 storage **[r5: two workgroups per CU]** | **{f(e['lasso_f32_storage']['value'])}** (391–398 across leases) | `k_fused_dense<4,1,1,16,0,4,1>` {f(e['lasso_f32_storage']['avg_launch_ms'],3)} ms (rocprofv3 {f(roc('void k_fused_dense<4, 1, 1, 16, 0, 4, 1>')[1],3)}; PMC {f(traffic('void k_fused_dense<4, 1, 1, 16, 0, 4, 1>'),2)} GB = 1.027×) | {f(e['lasso_f32_storage']['achieved_GB/s'],0)} GB/s | **{f(e['lasso_f32_storage']['frac'],3)}** (0.847–0.861 across leases) | 385–390, 0.83–0.85 |
-| **[r5]** set-up of a natural C2 solve (`extra.natural_run.lasso`) | {nat['iterations']} iterations: loop {f(nat['loop_s']*1e3)} ms, whole call {f(nat['whole_call_s']*1e3)} ms ⇒ **{f((nat['whole_call_s']-nat['loop_s'])*1e3)} ms** outside the loop | `k_setup_dense<8,2,16,512,2>` {f(roc('void k_setup_dense<8, 2, 16, 512, 2>')[1],2)} ms (rocprofv3, {roc('void k_setup_dense<8, 2, 16, 512, 2>')[0]} calls; PMC {f(traffic('void k_setup_dense<8, 2, 16, 512, 2>'),2)} GB) | {f(traffic('void k_setup_dense<8, 2, 16, 512, 2>')/roc('void k_setup_dense<8, 2, 16, 512, 2>')[1],0)} GB/s moved | — | 16.7 ms (three passes) |
+| **[r5]** set-up of a natural C2 solve (`extra.natural_run.lasso`) | {nat['iterations']} iterations: loop {f(nat['loop_s']*1e3)} ms, whole call {f(nat['whole_call_s']*1e3)} ms ⇒ **{f((nat['whole_call_s']-nat['loop_s'])*1e3)} ms** outside the loop | `k_setup_dense<8,2,16,512,2>` {f(roc('void k_setup_dense<8, 2, 16, 512, 2>')[1],2)} ms (rocprofv3, {roc('void k_setup_dense<8, 2, 16, 512, 2>')[0]} calls; PMC {f(traffic('void k_setup_dense<8, 2, 16, 512, 2>'),2)} GB) | {f(1e3*traffic('void k_setup_dense<8, 2, 16, 512, 2>')/roc('void k_setup_dense<8, 2, 16, 512, 2>')[1],0)} GB/s moved | — | 16.7 ms (three passes) |
 | **[r5]** device loop, `device_iters=64`, against the per-iteration path (itself on the one-pass kernel now); BASELINE config 1 = 512 × 1024 | 6000²: {dl['6000x6000']['per_iteration_launches']['iterations/s']:.0f} → {dl['6000x6000']['device_loop']['iterations/s']:.0f}; 4096²: {dl['4096x4096']['per_iteration_launches']['iterations/s']:.0f} → **{dl['4096x4096']['device_loop']['iterations/s']:.0f}**; 2048²: {dl['2048x2048']['per_iteration_launches']['iterations/s']:.0f} → {dl['2048x2048']['device_loop']['iterations/s']:.0f}; 512 × 1024: {dl['512x1024']['per_iteration_launches']['iterations/s']:.0f} → **{dl['512x1024']['device_loop']['iterations/s']:.0f}** (NumPy host loop on the same problem: {dl['512x1024']['numpy_host_loop']['iterations/s']:.0f}; 4900–15 500 across leases — OpenBLAS threading) | `k_run_dense<12/8/4/2>`: {dl['6000x6000']['device_loop']['us_per_iteration']:.1f} / {dl['4096x4096']['device_loop']['us_per_iteration']:.1f} / {dl['2048x2048']['device_loop']['us_per_iteration']:.1f} / {dl['512x1024']['device_loop']['us_per_iteration']:.1f} µs per iteration | 3.4 TB/s at 4096² (Infinity-Cache resident) | — | 13 850 at 4096² (per-iteration path) |
 | C2 matrix as 8 row blocks, one process | {f(e['inproc_8_row_blocks']['value'])} | 8 × {f(e['inproc_8_row_blocks']['avg_launch_ms'],3)} ms | {f(e['inproc_8_row_blocks']['achieved_GB/s'],0)} GB/s per block launch | {f(e['inproc_8_row_blocks']['frac'],3)} | 188–190 |
 | config 5's matrix (128 GiB) as 8 blocks on this GPU | {f(e['config5_matrix_on_one_gpu']['value'])} | 8 × {f(e['config5_matrix_on_one_gpu']['avg_launch_ms'],3)} ms | {f(e['config5_matrix_on_one_gpu']['achieved_GB/s'],0)} GB/s | {f(e['config5_matrix_on_one_gpu']['frac'],3)} | 51.1 |
