@@ -4,7 +4,8 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one FBS iteration of the product solver (fasta_python_amd.FBSolver.step) over a device-resident
+One "step" = one FBS iteration of the product solver (fasta_python_amd.FBSolver, driven as fasta() drives it: the library's
+host-side loop fh_iterate issues the launches and takes the reference's decisions) over a device-resident
 synthetic matrix: by default ONE launch of the one-pass kernel (both directions from a single read of A);
 `--fused off` gives the north-star structure of one K-fwd + one K-adj launch (+ one K-fwd per backtrack).
 N = 1: BASELINE.json configs[1], A = 65536 x 65536 float64 (32 GiB).  N > 1: the SAME matrix row-sharded
@@ -452,10 +453,13 @@ def timed_steps(make_solver, ctx, grp, warmup, steps, repeats=1, trace=False):
         with warnings.catch_warnings(), np.errstate(all="ignore"):
             warnings.simplefilter("ignore")
             solver.setup()
-            for _ in range(warmup):
-                ts = time.perf_counter()
-                solver.step()
-                step_ms.append((time.perf_counter() - ts) * 1e3)
+            if trace and rep == 0:
+                for _ in range(warmup):
+                    ts = time.perf_counter()
+                    solver.step()
+                    step_ms.append((time.perf_counter() - ts) * 1e3)
+            else:
+                solver.advance(warmup)
             ctx.timing_reset()
             ctx.timing_enable(True)
             bt0 = solver.total_backtracks
@@ -468,8 +472,7 @@ def timed_steps(make_solver, ctx, grp, warmup, steps, repeats=1, trace=False):
                     solver.step()
                     step_ms.append((time.perf_counter() - ts) * 1e3)
             else:
-                for _ in range(steps):
-                    solver.step()
+                solver.advance(steps)        # the product's default driver: the library's host-side loop (fh_iterate), K iterations, no Python in between
             ctx.sync(); grp.barrier()
             t1 = time.perf_counter()
             ctx.timing_enable(False)
@@ -580,7 +583,7 @@ def natural_runs(A, n, m_total):
         out[name] = {"iterations": int(k), "backtracks": int(c.backtracks), "loop_s": loop, "whole_call_s": wall,
                      "iterations_per_s": k / loop, "final_residual": float(c.residuals[k - 1]),
                      # (plain sums, not np.linalg.norm: a BLAS call here wakes OpenBLAS's worker threads, whose busy-wait under the box's
-                     # CPU quota stalls the main thread for tens of ms a few iterations into the NEXT solve -- scripts/natural_run.py)
+                     # CPU quota stalls the main thread for tens of ms a few iterations into the NEXT solve -- scripts/probes/natural_run.py)
                      "rel_error_vs_x_true": math.sqrt(float(np.sum((c.solution - x_true) ** 2)) / float(np.sum(x_true ** 2)))}
     out["note"] = ("fasta(A, ls.f, ls.gradf, reg.g, reg.prox, x0, tolerance=1e-5) on the resident matrix: loop_s = times[k] - times[0] "
                    "(the reference's print_info span), whole_call_s adds the setup passes (Lipschitz probes, init) and the D2H of the solution")
@@ -602,7 +605,7 @@ def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096), (6000,
             b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=0.01)
             loss, reg = fa.LeastSquares(b), fa.Shrink(0.02)
             rates = {}
-            for name, kw in (("per_iteration_launches", {}), ("device_loop", {"device_iters": per_launch})):
+            for name, kw in (("python_driver", {"device_iters": 0}), ("per_iteration_launches", {}), ("device_loop", {"device_iters": per_launch})):
                 best, steps_on_device = 0.0, 0
                 for _ in range(repeats):
                     np.random.seed(3)
@@ -618,6 +621,7 @@ def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096), (6000,
                     steps_on_device = solver.device_steps
                 rates[name] = {"iterations/s": best, "us_per_iteration": 1e6 / best, "iterations_inside_persistent_launches": steps_on_device}
             rates["speedup"] = rates["device_loop"]["iterations/s"] / rates["per_iteration_launches"]["iterations/s"]
+            rates["library_loop_vs_python_driver"] = rates["per_iteration_launches"]["iterations/s"] / rates["python_driver"]["iterations/s"]
             if (m, n) == (512, 1024):
                 # BASELINE config 1 as BASELINE states it: the same problem on the NumPy CPU path -- the product's generic host loop with the
                 # reference's closure forms (examples/sparse_least_squares.py:41-44) on a host copy of the matrix; no GPU involved
@@ -639,7 +643,9 @@ def device_loop_runs(grp, sizes=((512, 1024), (2048, 2048), (4096, 4096), (6000,
             out[f"{m}x{n}"] = rates
         finally:
             A.close()
-    out["note"] = (f"{iters} iterations, tolerance 0, adaptive FBS with backtracking; device_loop = fasta(..., device_iters={per_launch}): backtracking test, "
+    out["note"] = (f"{iters} iterations, tolerance 0, adaptive FBS with backtracking; python_driver = device_iters=0 (FBSolver.step between all launches, rounds 1-5); "
+                   "per_iteration_launches = the default (one launch per iteration issued by the library's host-side loop fh_iterate: same launches, same decisions, "
+                   f"bit-identical histories); device_loop = fasta(..., device_iters={per_launch}): backtracking test, "
                    "Barzilai-Borwein step, residuals, best iterate and the stop rule are decided on the device, histories come back once per launch; opt-in")
     return out
 
@@ -719,6 +725,74 @@ def run_tv(args, grp, steps, warmup, fused, accelerate, repeats=3):
                                   "note": "SURVEY.md 8(d) materialised-vector model (136*P per iteration + 64*P per backtrack) / wall-clock"},
         "side": side, "spread": t["spread"],
     }
+
+
+def tv_small_runs(grp, side=512, iters=600, repeats=3):
+    """The stencil at the REFERENCE's own size (fasta/examples/tv_denoising.py:113-125 denoises the 512 x 512 `ascent()`; here the same
+    checkerboard + noise as the 8192^2 runs): one sweep moves 40 P = 10.5 MB (~2 us of HBM time), so an iteration is what it costs to
+    launch one kernel and get 16 scalars back.  Python driver (device_iters=0) and the library's host-side loop (default) side by side, the
+    sweep's own HIP-event time next to both, adaptive and FISTA; plus the natural run (default options, tolerance 1e-5)."""
+    import numpy as np
+    import fasta_python_amd as fa
+    from fasta_python_amd import hip
+    from fasta_python_amd.examples.tv_denoising import checkerboard
+    np.random.seed(7)
+    M = checkerboard(side, side, max(1, side // 32))
+    M += 0.1 * np.random.standard_normal(M.shape)
+    mu = 0.1
+    A = fa.GradDivMap(M.shape, device=grp.local_rank)
+    out = {}
+    try:
+        loss, reg = fa.LeastSquares(M / mu), fa.TVDualBall()
+        x0 = np.zeros(M.shape + (2,))
+        for mode, acc in (("adaptive", False), ("accelerated", True)):
+            res = {}
+            for name, kw in (("python_driver", {"device_iters": 0}), ("library_loop", {})):
+                best, sweep_us, launches, bts = 0.0, None, 0, 0
+                for rep in range(repeats + 1):                   # the last pass carries the HIP events (two records per launch cost a few us: kept out of the rate)
+                    timed = rep == repeats
+                    np.random.seed(3)
+                    solver = fa.FBSolver(A, loss, reg, x0, adaptive=not acc, accelerate=acc, verbose=False, max_iters=iters, tolerance=0.0, **kw)
+                    with warnings.catch_warnings(), np.errstate(all="ignore"):
+                        warnings.simplefilter("ignore")
+                        solver.setup()
+                        solver.advance(60)                       # into the backtracking regime, as the 8192^2 runs
+                        A.ctx.timing_reset(); A.ctx.timing_enable(timed)
+                        bt0, i0 = solver.total_backtracks, solver.i
+                        A.ctx.sync()
+                        t0 = time.perf_counter()
+                        solver.advance(iters)
+                        A.ctx.sync()
+                        el = time.perf_counter() - t0
+                        A.ctx.timing_enable(False)
+                    if timed:
+                        ms, cnt = A.ctx.timing_get(hip.K_FUSED)
+                        sweep_us, launches = (ms / cnt * 1e3 if cnt else None), cnt
+                    elif (solver.i - i0) / el > best:
+                        best, bts = (solver.i - i0) / el, solver.total_backtracks - bt0
+                per_launch = 1e6 * (iters - 60) / best / launches if launches else None
+                res[name] = {"iterations/s": best, "us_per_iteration": 1e6 / best, "backtracks": int(bts), "launches": int(launches),
+                             "us_per_launch_wallclock": per_launch, "sweep_us_hip_events": sweep_us,
+                             "launch_to_sweep_ratio": per_launch / sweep_us if sweep_us and per_launch else None}
+            res["library_loop_vs_python_driver"] = res["library_loop"]["iterations/s"] / res["python_driver"]["iterations/s"]
+            out[mode] = res
+        np.random.seed(3)
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = fa.fasta(A, loss.f, loss.gradf, reg.g, reg.prox, x0, verbose=False, tolerance=1e-5, backend="hip")
+        wall = time.perf_counter() - t0
+        k = c.iteration_count
+        out["natural_run"] = {"iterations": int(k), "backtracks": int(c.backtracks), "loop_s": c.times[k] - c.times[0], "whole_call_s": wall,
+                              "iterations_per_s": k / (c.times[k] - c.times[0])}
+    finally:
+        A.close()
+    P = side * side
+    out["side"], out["algorithmic_bytes_per_sweep"] = side, {"adaptive": 40 * P, "accelerated": 56 * P}
+    out["note"] = (f"TV denoising {side}x{side} float64 -- the reference example's own image size (tv_denoising.py:113-125) -- {iters - 60} timed iterations after 60 "
+                   "warm-up ones, tolerance 0, best of 3; k_tv_onepass moves 40 P (adaptive) / 56 P (FISTA) bytes per sweep; at this size the iteration is the launch + "
+                   "the one synchronisation, not the sweep: launch_to_sweep_ratio = wall clock per launch / the sweep's HIP-event time")
+    return out
 
 
 def tv_line(args, r, accelerate):
@@ -950,6 +1024,8 @@ def main(argv=None):
                              "launches/s = the rate of a stretch without backtracking (what round 2 reported)")
                 s["vs_materialised_model"] = r["vs_materialised_model"]
                 extra[key] = s
+            if "tv_512" not in args.skip_extra.split(","):
+                extra["tv_512"] = tv_small_runs(grp)
             extra["natural_run"] = natural_runs(A, n, m_total)
             if "device_loop" not in args.skip_extra.split(","):
                 extra["device_loop"] = device_loop_runs(grp)

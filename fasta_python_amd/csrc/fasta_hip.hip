@@ -306,6 +306,9 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
       if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->slots_sig = 0; }
       return 0;
+    case FH_TUNE_RUN_MAX_N:
+      if (value < 0 || value > 7168) return fail(FH_E_ARG, "RUN_MAX_N must be in [0, 7168] (0 = the measured default; 7168 = the widest row fh_run has a kernel for)");
+      c->run_max_n = (int)value; return 0;
     case FH_TUNE_FUSED_VARIANT:
       // (bits 64 / 128 were test hooks until round 4: a caller's variant word must not be able to switch the one-pass kernel off)
       if (value & 0xFFC1) return fail(FH_E_ARG, "FUSED_VARIANT: only the scheduling bits 2, 4, 8, 16, 32 are defined (got 0x%llx)", (unsigned long long)(value & 0xFFFF));
@@ -313,7 +316,7 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
     case FH_TUNE_TEST_HOOKS:        // not in the public header (csrc/fh_experimental.h): fault injection for the test-suite
-      if (value & ~3ll) return fail(FH_E_ARG, "TEST_HOOKS: bits 1 and 2 only");
+      if (value & ~0xFF0Fll) return fail(FH_E_ARG, "TEST_HOOKS: bits 1, 2, 4, 8 and the attempt byte (bits 8..15) only");
       if ((int)value != c->test_hooks) { c->test_hooks = (int)value; c->coresident = -1; }
       return 0;
     default: return fail(FH_E_ARG, "unknown tuning key %d", key);
@@ -979,6 +982,7 @@ extern "C" int fh_step_accel(fh_ctx* c, double tau, double coef, int restart, do
 }
 
 // ---- the loop on the device (csrc/fh_run.h) --------------------------------------------------------------------------------------------
+static const int kRunDefaultMaxN = 6144;
 struct RunEntry { int ppt; void (*kernel)(const RunP); };
 static const RunEntry kRunTable[] = {{1, k_run_dense<1>}, {2, k_run_dense<2>}, {4, k_run_dense<4>}, {5, k_run_dense<5>},
                                      {6, k_run_dense<6>}, {7, k_run_dense<7>}, {8, k_run_dense<8>},
@@ -991,6 +995,9 @@ static const RunEntry* run_entry(fh_ctx* c) {
   // a workgroup owns whole rows: 16-byte pieces per lane = the first table entry that covers the row (lanes past the row's end re-read its last piece)
   const uint64_t pieces = round_up(c->n, 16) / 2;
   if (c->ld % 2 || pieces == 0 || pieces > (uint64_t)FH_WG * 14) return nullptr;
+  // ... up to the width where the persistent launch still beats one launch per iteration issued by fh_iterate (FH_TUNE_RUN_MAX_N overrides:
+  // profiles/r06_device_loop.txt has both drivers at every width up to 7168)
+  if (c->n > (uint64_t)(c->run_max_n > 0 ? c->run_max_n : kRunDefaultMaxN)) return nullptr;
   const int need = (int)((pieces + FH_WG - 1) / FH_WG);
   for (const RunEntry& e : kRunTable) if (e.ppt >= need) return &e;
   return nullptr;
@@ -1057,15 +1064,29 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   HIP_TRY(hipMemsetAsync(c->gridbar, 0, GB_WORDS * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->counters + CNT_RUN_BAR, 0, 2 * sizeof(unsigned), c->stream));
   p.bar = c->gridbar; p.err = c->counters + CNT_RUN_BAR + 1;
+  p.hook_attempt = FH_HOOK_RUN_ATTEMPT(c->test_hooks);
   t_begin(c, FH_K_FUSED);
   e->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
   FH_TRY(finish(c));
   hs = (RunState*)c->run_st_host;                       // the state on exit, written by the launch
-  if (hs->stopped == 3)
-    return fail(FH_E_STATE, "fh_run: a grid barrier of the persistent launch timed out (workgroups not co-resident?) -- the solver state is undefined; call fh_init");
-  // adopt the state the launch left: buffer roles and indices exactly as fh_commit would have left them
+  // what the launch wrote back is checked before a single index of it is used: the block was poisoned (0xFF) before the launch
+  {
+    bool sane = (hs->stopped == 0 || hs->stopped == 1 || hs->stopped == 3) && hs->iteration >= state->iteration &&
+                hs->iteration - state->iteration <= (uint64_t)max_steps && hs->backtracks >= state->backtracks &&
+                hs->xi >= 0 && hs->xi < 3 && hs->ti >= 0 && hs->ti < 3 && hs->bi >= 0 && hs->bi < 3 && hs->xi != hs->ti &&
+                (hs->pc | 1) == 1 && (hs->gc | 1) == 1 && (hs->zc | 1) == 1;
+    unsigned seen = 0;
+    for (int q = 0; q < 5 && sane; ++q) { if (hs->perm[q] < 0 || hs->perm[q] >= 5) sane = false; else seen |= 1u << hs->perm[q]; }
+    if (!sane || seen != 31u) {
+      c->slots_sig = 0;
+      return fail(FH_E_STATE, "fh_run: the persistent launch did not write a valid solver state back (stopped = %d) -- the state is undefined; call fh_init", hs->stopped);
+    }
+  }
+  // adopt the state the launch left: buffer roles and indices exactly as fh_commit would have left them.  After a grid-barrier timeout
+  // (stopped == 3) that is the state of the last COMPLETED iteration: an attempt writes only buffers that are not x0 / g0 / x_accel0 /
+  // z_accel0 (csrc/fh_run.h), so everything the next iteration reads is intact, and tau_next is the step the interrupted iteration began with.
   double* nx[5];
   for (int q = 0; q < 5; ++q) nx[q] = nb[hs->perm[q]];
   c->X[0] = nx[0]; c->X[1] = nx[1]; c->X[2] = nx[2]; c->P[0] = nx[3]; c->P[1] = nx[4];
@@ -1078,6 +1099,32 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   memcpy(state->f_window, hs->f_window, sizeof(hs->f_window));
   memcpy(history, c->run_hist, (size_t)done * FR_HIST * sizeof(double));
   *steps_done = done;
+  if (hs->stopped == 3) {
+    c->run_timeouts += 1;
+    // One corner: a workgroup whose wait ended in time may have begun the NEXT attempt before it ran into the missing one, and then its rows of
+    // that attempt's z target -- the completed iteration's z_accel0, which only FISTA reads -- are overwritten.  z_accel0 = A x_accel0: form it again.
+    if (o->accelerate) FH_TRY(op_fwd(c, 1, 0.0, c->P[c->pc], nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 0));
+    FH_TRY(finish(c));
+    return fail(FH_E_TIMEOUT, "fh_run: a grid barrier of the persistent launch timed out after %d completed iterations (workgroups not co-resident?); "
+                              "the state of the last completed iteration is in place -- continue with fh_iterate / fh_step", done);
+  }
+  return 0;
+}
+
+// How often this context recovered from an in-launch timeout: what = 0 level searches that fell back to one workgroup, 1 level searches
+// that found no level (FH_E_TIMEOUT), 2 persistent launches of fh_run that ended in a barrier timeout (FH_E_TIMEOUT, state recovered).
+extern "C" int fh_recovered_count(fh_ctx* c, int what, uint64_t* count) {
+  if (!c || !count || what < 0 || what > 2) return fail(FH_E_ARG, "fh_recovered_count: bad argument");
+  *count = 0;
+  for (int k = 0; k < nshards(c); ++k) {
+    fh_ctx* s = shard_of(c, k);
+    if (what == 2) { *count += s->run_timeouts; continue; }
+    FH_TRY(use_device(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned w[2] = {0, 0};
+    HIP_TRY(hipMemcpy(w, s->counters + CNT_DIAG, sizeof(w), hipMemcpyDeviceToHost));
+    *count += w[what];
+  }
   return 0;
 }
 
@@ -1361,3 +1408,5 @@ extern "C" int fh_stream_read_ms(fh_ctx* c, int reps, double* ms_per_pass, uint6
   if (bytes_per_pass) *bytes_per_pass = npieces * 16;
   return 0;
 }
+
+#include "fh_host_iterate.h"

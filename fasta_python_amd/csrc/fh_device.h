@@ -92,8 +92,10 @@ __device__ __forceinline__ double prox_scalar(double x, const ProxP& px, double 
   if (KIND == PX_SHRINK) return sgn(x) * fmax(fabs(x) - px.thr, 0.0);
   if (KIND == PX_NONNEG) return fmax(x, 0.0);
   if (KIND == PX_BOX)    return fmin(fmax(x, px.lo), px.hi);
-  if (KIND == PX_LINF)   return level > 0.0 ? fmin(fabs(x), level) * sgn(x) : 0.0;
-  if (KIND == PX_L1BALL) return x - (level > 0.0 ? fmin(fabs(x), level) * sgn(x) : 0.0);
+  // (a level <= 0 means "the zero vector", proximal.py:28-31; a NaN level -- a search that could not finish -- is PROPAGATED, so that it
+  //  reaches every sum of the step and the host's check instead of passing for "level <= 0")
+  if (KIND == PX_LINF)   return level > 0.0 ? fmin(fabs(x), level) * sgn(x) : (level != level ? level : 0.0);
+  if (KIND == PX_L1BALL) return x - (level > 0.0 ? fmin(fabs(x), level) * sgn(x) : (level != level ? level : 0.0));
   return x;
 }
 
@@ -270,7 +272,7 @@ __device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned total, v
 // A generation barrier for co-resident workgroups.  G atomic adds on ONE address cost 3.6 us at G = 256 and 8.0 us at G = 512 (same-address
 // atomics serialise at the memory side); with the arrivals spread over GB_GROUPS counters on separate 128-byte lines -- workgroup b arrives at
 // counter b % GB_GROUPS, the last arriver of a group at the top counter, the last of those publishes the generation in a release word that
-// everybody polls with plain write-through-coherent loads -- the same barrier costs 1.5 / 1.6 us (scripts/bench_mem/gridbar.hip,
+// everybody polls with plain write-through-coherent loads -- the same barrier costs 1.5 / 1.6 us (scripts/probes/bench_mem/gridbar.hip,
 // profiles/r05_gridbar.txt; polling the release word with SCALAR glc loads instead: 17-45 us, hundreds of pollers on one line).
 // All counters only grow: `gen` = 1, 2, 3, ... counts the barriers of the launch; the host zeroes the GB_WORDS words before the launch.
 // Bounded: after FT_SPIN_TICKS-like `budget` ticks of the 100 MHz clock the caller's `err` word is set and false is returned (every

@@ -10,7 +10,12 @@
 //       FH_TUNE_TV_SLOTS   = 15   persistent form: at most this many workgroups per CU walk the chunk ids band-major
 // (2) Test hooks (always compiled, never documented in the public header; tests/ sets them through fh_set_tuning):
 //       FH_TUNE_TEST_HOOKS = 0x7E57   bit 1: member TEAM-1 of team 0 withholds its first partial (the bounded spins must end the
-//                                     launch with the timeout word set); bit 2: this context's co-residency probe answers "no".
+//                                     launch with the timeout word set); bit 2: this context's co-residency probe answers "no";
+//                                     bit 4: the multi-workgroup level search's last workgroup withholds its first record (the others
+//                                     time out and search alone: same level); bit 8: ... and that fall-back is off (NaN level ->
+//                                     FH_E_TIMEOUT); bits 8..15: (value >> 8) & 0xFF = the 1-based attempt of fh_run's persistent
+//                                     launch at whose first grid barrier the last workgroup stays away (the launch ends with
+//                                     stopped = 3 after the bounded spins; 0 = off).
 #pragma once
 enum fh_experimental_key {
   FH_TUNE_TV_ZFREE = 10,
@@ -21,3 +26,6 @@ enum fh_experimental_key {
 };
 #define FH_HOOK_WITHHOLD_PARTIAL 1
 #define FH_HOOK_PROBE_SAYS_NO 2
+#define FH_HOOK_LEVEL_WITHHOLD 4
+#define FH_HOOK_LEVEL_NO_FALLBACK 8
+#define FH_HOOK_RUN_ATTEMPT(h) (((h) >> 8) & 0xFF)

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
   // The slot line is polled with SCALAR loads (`s_load_dwordx16 glc`: past the scalar cache, all eight slots at
   // once): they count on lgkmcnt, so the poll neither waits for this wave's prefetched rows nor for its stores --
   // a vector poll's `s_waitcnt vmcnt(0)` did both (vmcnt retires in order), which put one HBM latency into every
-  // trip.  Measured hand-off (scripts/bench_mem/handoff.hip): sc1 store -> s_load glc ~0.5 us within and across
+  // trip.  Measured hand-off (scripts/probes/bench_mem/handoff.hip): sc1 store -> s_load glc ~0.5 us within and across
   // XCDs, sc1 store -> sc1 vector load 0.6-0.9 us.  The loop itself is plain C around the asm load: it contains no
   // compiler-visible vector memory operation, so hipcc's vmcnt bookkeeping for the row buffers stays exact.
   typedef unsigned ft_line __attribute__((ext_vector_type(16)));

@@ -174,7 +174,7 @@ struct fh_ctx {
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
   int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
   int test_hooks = 0;        // FH_TUNE_TEST_HOOKS (csrc/fh_experimental.h): fault injection, set by the test-suite only
-  int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/fused_small_m.py)
+  int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/probes/fused_small_m.py)
   // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
   // the host fills both with the sentinel only when this signature (workspace, layout) changes or a launch timed out
   double* slotbuf = nullptr;     // dedicated allocation: the shared workspace `ws` is scribbled over by every other kernel
@@ -196,6 +196,7 @@ struct fh_ctx {
   int nranks = 1, rank = 0;
   int ncu = 0;               // compute units of the device (fused one-pass kernel: one workgroup per CU)
   int coresident = -1;       // -1 = not probed yet; 1 / 0 = fused_ncu() workgroups can / cannot run side by side (co_resident())
+  int run_max_n = 0;         // FH_TUNE_RUN_MAX_N: widest row fh_run takes (0 = kRunDefaultMaxN)
   int fused_cus = 0;         // FH_TUNE_FUSED_CUS: the one-pass dense kernel uses at most this many CUs (0 = all the device reports)
   // ---- in-process row sharding (fh_create_ex with ndev > 1; SURVEY.md 8(b)/(e): one host thread, one context per device) ----
   // A context created over several devices is a SHELL: it owns one child context per entry of dev_ids (`shards`), each holding
@@ -214,6 +215,7 @@ struct fh_ctx {
   double* lvl_rec = nullptr;         // multi-workgroup level search: per-pass records and counters (allocated on first use, counters kept zero)
   unsigned* lvl_cnt = nullptr;
   double* selftest_buf = nullptr;    // fh_comm_selftest's scratch (freed before it returns)
+  uint64_t run_timeouts = 0;         // persistent launches of fh_run that ended in a grid-barrier timeout (fh_recovered_count)
   bool pending_step = false;         // fh_step_begin has issued a step whose fh_step_end is still to come (every other entry point refuses)
   bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)
   bool owns_stream = true;           // false in shards 1.. of an emulated group (they run on shard 0's stream)
@@ -226,7 +228,8 @@ static inline fh_ctx* shard_of(fh_ctx* c, int k) { return c->shards.empty() ? c 
 static inline bool row_sharded(const fh_ctx* c) { return c->comm != nullptr || c->owner != nullptr; }
 
 static const int kCounterWords = 8192;
-enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_PROBE = 12, CNT_RUN_BAR = 14, CNT_ADJ_CC = 16 };
+enum { CNT_FWD = 0, CNT_ADJ_FIN = 1, CNT_AUX = 2, CNT_FUSED_BAR = 4, CNT_FUSED_ERR = 8, CNT_PROBE = 12, CNT_RUN_BAR = 14, CNT_ADJ_CC = 16,
+       CNT_DIAG = kCounterWords - 8 };     // the last 8 words only ever grow: [0] level searches that fell back to one workgroup, [1] ... that found no level (fh_recovered_count)
 
 static inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 
@@ -377,7 +380,14 @@ static int issue_scalars(fh_ctx* c) {
 static int collect_scalars(fh_ctx* c, double* scalars) {
   FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
   // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors
-  if (scalars) memcpy(scalars, shard_of(c, 0)->hscal, FH_NSCALARS * sizeof(double));
+  fh_ctx* s0 = shard_of(c, 0);
+  if (scalars) memcpy(scalars, s0->hscal, FH_NSCALARS * sizeof(double));
+  // The clipping level of the l-infinity prox / l1-ball projection travels with every forward launch (FH_S_ALPHA).  NaN = the level
+  // search could not finish (csrc/fh_prox.h: a hand-off timed out AND the single-workgroup fall-back was not available); prox_scalar
+  // has propagated it into every output of the launch.  Typed, so that a caller can tell it from a device fault.
+  if ((s0->prox_kind == FH_PROX_LINF || s0->prox_kind == FH_PROX_L1BALL) && s0->hscal[FH_S_ALPHA] != s0->hscal[FH_S_ALPHA])
+    return fail(FH_E_TIMEOUT, "the clipping-level search of the l-infinity prox / l1-ball projection did not finish (hand-off between its workgroups "
+                              "timed out and no fall-back was possible): the step's outputs are NaN");
   return 0;
 }
 static int fetch_scalars(fh_ctx* c, double* scalars) {

@@ -107,7 +107,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   }
   p.slab_rows = slab;
   p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
-  if (p.ncc + CNT_ADJ_CC > (uint32_t)kCounterWords) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
+  if (p.ncc + CNT_ADJ_CC > (uint32_t)CNT_DIAG) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
   p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.loss = c->loss_kind; p.accel = io.accel; p.coef = io.coef;
   p.mode = io.mode; p.tau = io.tau;
   p.x0 = io.x0; p.xp = io.xp; p.xacc0 = io.xacc0; p.xhat = io.xhat; p.x1 = io.x1; p.g1 = io.g1;
@@ -172,10 +172,11 @@ static int launch_level_search(fh_ctx* c, double tau) {
       HIP_TRY(hipMalloc((void**)&c->lvl_cnt, (LVL_MAXPASS + 1) * sizeof(unsigned)));
       HIP_TRY(hipMemsetAsync(c->lvl_cnt, 0, (LVL_MAXPASS + 1) * sizeof(unsigned), c->stream));
     }
-    LevelWs ws = {c->lvl_rec, c->lvl_cnt};
+    LevelWs ws = {c->lvl_rec, c->lvl_cnt, c->counters + CNT_DIAG};
     const unsigned G = (n + LVL_MEPT * LVL_WG - 1) / (LVL_MEPT * LVL_WG);
+    const int hooks = ((c->test_hooks & FH_HOOK_LEVEL_WITHHOLD) ? LVL_HOOK_WITHHOLD : 0) | ((c->test_hooks & FH_HOOK_LEVEL_NO_FALLBACK) ? LVL_HOOK_NO_FALLBACK : 0);
     t_begin(c, FH_K_LEVEL);
-    k_level_search_multi<<<dim3(G), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out, ws);
+    k_level_search_multi<<<dim3(G), dim3(LVL_WG), 0, c->stream>>>(x0, g0, n, tau, radius, out, ws, hooks);
     t_end(c, FH_K_LEVEL);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -676,7 +677,7 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
     p.rows_wg = std::min(p.H, std::max(32u, (p.H + chunks - 1) / chunks));
   }
   // rows per trip / rotating trip buffers: 2 rows, load-then-consume for the plain sweep; 4 rows x 3 rotating buffers with FISTA
-  // (two streams to read): profiles/r03_tune_tv.txt.  Every combination produces the same bits (scripts/tune_tvz.py).
+  // (two streams to read): profiles/r03_tune_tv.txt.  Every combination produces the same bits (scripts/probes/tune_tvz.py).
   const int tvu = c->tv_u ? c->tv_u : (accel ? 4 : 2);
   if (accel) { p.p1 = nq(c, c->lq1); p.p0 = nq(c, c->lq0); p.pn = nq(c, c->lqn); p.cprev = c->lc; }
   else { p.p1 = c->X[c->xi]; p.p0 = c->X[c->xi]; p.pn = c->P[c->pc ^ 1]; p.cprev = 0.0; }

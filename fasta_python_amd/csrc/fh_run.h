@@ -22,7 +22,8 @@
 //             arithmetic, same decision everywhere.  Workgroup 0 also writes the iteration's history record.
 // Vectors that one workgroup writes and another reads in the NEXT attempt (g1, x1, xprox, xhat) are stored write-through (sc1) and
 // loaded past L1 (sc1), as the CDNA4 guide's Guideline 16 prescribes for in-launch hand-offs; barriers are generation counters with
-// bounded spins (a timeout ends the launch with `stopped = 3`).
+// bounded spins (a timeout ends the launch with `stopped = 3`; the host adopts the state of the last completed iteration and the caller carries
+// on with the per-iteration path: csrc/fasta_hip.hip:fh_run).
 // Measured and NOT shipped (round 5): rows of 4096 < n <= 8192 columns with 512-thread workgroups (two waves per SIMD, x0 / g0 in LDS):
 // correct, but hipcc spills ~210 registers per lane at two waves per SIMD and an iteration at 8192^2 takes 209 us against 136 us on the
 // per-iteration path (profiles/r05_device_loop.txt).
@@ -47,7 +48,9 @@ struct RunOpts {
 struct RunState {            // survives between launches: passed in by value, written back to host-mapped memory at the end
   double tau_next, alpha1, max_residual, best_quality;
   unsigned long long iteration, backtracks;
-  int stopped;               // 0 = ran out of steps, 1 = the stop rule fired, 3 = a grid barrier timed out (state invalid)
+  int stopped;               // 0 = ran out of steps, 1 = the stop rule fired, 3 = a grid barrier timed out: the state is that of the last COMPLETED
+                             //     iteration (an attempt writes only the buffers that are NOT x0 / g0 / x_accel0 / z_accel0), tau_next the step the
+                             //     interrupted iteration started with
   int xi, ti, bi, pc, gc, zc, last_accel;
   int perm[5];               // which of the five physical n-side buffers sits in X[0], X[1], X[2], P[0], P[1]
   double f_window[FR_WINDOW_MAX];   // f_hist[j] at j % FR_WINDOW_MAX for the last `window` iterations
@@ -70,6 +73,7 @@ struct RunP {
   double* gpart; double* red;
   unsigned* bar;             // GB_WORDS words of the two-level grid barrier (fh_device.h:grid_barrier2), zero on entry
   unsigned* err;
+  int hook_attempt;          // test hook (FH_TUNE_TEST_HOOKS bits 8..15): the last workgroup stays away from barrier 1 of this attempt (1-based; 0 = off)
 };
 
 // (the grid barriers of the loop: grid_barrier2 of fh_device.h -- two-level, 1.5 us instead of 3.6 us at 256 workgroups)
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
     for (int k = 0; k < NB - 1; ++k) load_row(B[k], min((uint32_t)k, r_last));
   }
   bool load_x = true, load_g = true;       // (uniform) the LDS copies of x0 / x_accel0 resp. g0 must be (re)read from memory
+  double tau_iter = tau;                   // the step the current ITERATION started with (what a caller that redoes it after a timeout must use)
   while (steps < p.max_steps && !stopped) {
     // ================= one attempt with step `tau` =================
     FR_STAMP(7);
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       if (c0 + k * FH_WG < p.ld2) store_partial16(reinterpret_cast<d2*>(p.gpart) + (uint64_t)team * p.nv2, c0 + k * FH_WG, ga[k]);
     if (tid == 0) { store_partial(red + (uint64_t)team * 16, fs); store_partial(red + (uint64_t)team * 16 + 7, fsa); }
     FR_STAMP(1);
+    if (p.hook_attempt && (int)attempt == p.hook_attempt && team == G - 1u && G > 1u) { stopped = 3; break; }      // (test hook: this workgroup never arrives)
     if (!grid_barrier2(p.bar, ++nbar, p.err, FT_SPIN_TICKS, s_flag)) { stopped = 3; break; }
     FR_STAMP(2);
 
@@ -430,7 +436,9 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
         out[0] = 0.0; out[1] = tau_nx; out[2] = better ? 1.0 : 0.0; out[3] = stop ? 1.0 : 0.0; out[4] = f1;
         if (team == 0) {
           double* h = p.hist + (uint64_t)steps * FR_HIST;
-          h[0] = resid; h[1] = norm_resid; h[2] = tau; h[3] = f1; h[4] = objective; h[5] = (double)bt; h[6] = alpha0; h[7] = better ? 1.0 : 0.0;
+          const bool restarted = o.accelerate && o.restart && rdot > 1E-30;      // (:231-233; the reference prints "Restarted acceleration.")
+          h[0] = resid; h[1] = norm_resid; h[2] = tau; h[3] = f1; h[4] = objective; h[5] = (double)bt; h[6] = alpha0;
+          h[7] = (better ? 1.0 : 0.0) + (restarted ? 2.0 : 0.0);
         }
       }
 #pragma unroll
@@ -460,12 +468,20 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
       const d2 xpv = s_x[k * FH_WG + tid];
       d2 x1v = xpv;
       if (o.accelerate) {
-        const d2 xav = BIG ? load_partial16(reinterpret_cast<const d2*>(xacc0), pc[k]) : s_xa[BIG ? 0 : k * FH_WG + tid];
-        x1v.x = extrapolate(xpv.x, xav.x, coef); x1v.y = extrapolate(xpv.y, xav.y, coef);
-        const uint32_t c = c0 + k * FH_WG;
-        if (!(2u * c < p.n)) x1v.x = 0.0;
-        if (!(2u * c + 1u < p.n)) x1v.y = 0.0;
-        if constexpr (!BIG) s_xa[k * FH_WG + tid] = xpv;
+        if constexpr (BIG) {
+          // x1 itself, as phase B stored it (write-through, before barrier 2; the same extrapolate() arithmetic, zero past the row's end).
+          // NOT re-derived from x_accel0 here: that buffer is the NEXT attempt's prox target, which workgroup 0 starts to overwrite in its
+          // phase A with no grid barrier in between -- a workgroup that reached this line late would extrapolate from the new prox output
+          // (round-5 advisor finding).  x1's buffer becomes x0 and is not written again before the next commit.
+          x1v = load_partial16(reinterpret_cast<const d2*>(x1_out), pc[k]);
+        } else {
+          const d2 xav = s_xa[k * FH_WG + tid];
+          x1v.x = extrapolate(xpv.x, xav.x, coef); x1v.y = extrapolate(xpv.y, xav.y, coef);
+          const uint32_t c = c0 + k * FH_WG;
+          if (!(2u * c < p.n)) x1v.x = 0.0;
+          if (!(2u * c + 1u < p.n)) x1v.y = 0.0;
+          s_xa[k * FH_WG + tid] = xpv;
+        }
       }
       s_x0[k * FH_WG + tid] = x1v;
     }
@@ -477,6 +493,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
     for (int k = 0; k < 3; ++k) if (k != xi && k != bi) { ti = k; break; }
     zc ^= 1; gc ^= 1;
     tau = s_ctl[1];
+    tau_iter = tau;
     it += 1u;
     steps += 1;
     if (uni(s_ctl[3] != 0.0 ? 1 : 0)) stopped = 1;
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(FH_WG, 1) void k_run_dense(const RunP p) {
   if (team == 0 && tid == 0) {
     {
       RunState* d = p.st_out;
-      d->tau_next = tau; d->alpha1 = alpha1; d->max_residual = max_residual; d->best_quality = best_quality;
+      d->tau_next = stopped == 3 ? tau_iter : tau; d->alpha1 = alpha1; d->max_residual = max_residual; d->best_quality = best_quality;
       d->iteration = it0 + it; d->backtracks = bt0 + total_bt; d->stopped = stopped;
       d->xi = xi; d->ti = ti; d->bi = bi; d->pc = pcx; d->gc = gc; d->zc = zc; d->last_accel = last_accel;
 #pragma unroll

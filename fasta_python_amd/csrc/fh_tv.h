@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
 #endif
   if constexpr (NB == 3) {
     // three rotating trips: two stay in flight behind the one being consumed -- the shape that sustains this read/write mix
-    // best in scripts/bench_mem/mixprobe.hip (in the burst form below the waves sit in s_waitcnt 65 % of their cycles)
+    // best in scripts/probes/bench_mem/mixprobe.hip (in the burst form below the waves sit in s_waitcnt 65 % of their cycles)
     Trip T0, T1, T2;
     load_trip(T0, 0);
     load_trip(T1, TV_U);

@@ -24,12 +24,19 @@ NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED, K_HOST_ISSUE, K_LEVEL = range(7)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
- TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS) = range(17)
+ TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS, TUNE_RUN_MAX_N) = range(18)
 # keys 10, 13, 14, 15 (TUNE_TV_ZFREE / _LDS_PAD / _RING / _SLOTS) are NOT in include/fasta_hip.h: experimental forms of the stencil sweep,
 # accepted only by libfasta_hip_experimental.so (csrc/fh_experimental.h); the shipped library answers FH_E_ARG
 EXPERIMENTAL_KEYS = (TUNE_TV_ZFREE, TUNE_TV_LDS_PAD, TUNE_TV_RING, TUNE_TV_SLOTS)
-TUNE_TEST_HOOKS = 0x7E57             # tests only (csrc/fh_experimental.h): 1 = a withheld team partial, 2 = the co-residency probe says no
-HOOK_WITHHOLD_PARTIAL, HOOK_PROBE_SAYS_NO = 1, 2
+TUNE_TEST_HOOKS = 0x7E57             # tests only (csrc/fh_experimental.h): 1 = a withheld team partial, 2 = the co-residency probe says no,
+#                                      4 = the level search's last workgroup withholds its record, 8 = ... and its fall-back is off,
+#                                      attempt << 8 = fh_run's last workgroup stays away from that attempt's first grid barrier
+HOOK_WITHHOLD_PARTIAL, HOOK_PROBE_SAYS_NO, HOOK_LEVEL_WITHHOLD, HOOK_LEVEL_NO_FALLBACK = 1, 2, 4, 8
+HOOK_RUN_ATTEMPT_SHIFT = 8
+E_ARG, E_STATE, E_RCCL, E_TIMEOUT = 10001, 10002, 10003, 10004
+LAUNCH_SEPARATE, LAUNCH_ONEPASS_ALWAYS, LAUNCH_ONEPASS_SPECULATIVE, LAUNCH_PAIR = range(4)     # fh_run_opts.launch_mode (fh_iterate)
+LAUNCH_MODES = {None: LAUNCH_SEPARATE, "always": LAUNCH_ONEPASS_ALWAYS, "speculative": LAUNCH_ONEPASS_SPECULATIVE, "pair": LAUNCH_PAIR}
+RECOVERED_LEVEL_FALLBACK, RECOVERED_LEVEL_FAILED, RECOVERED_RUN_TIMEOUT = range(3)
 UNIQUE_ID_BYTES = 128
 DTYPE_F64, DTYPE_F32_STORAGE = 0, 1
 CREATE_RCCL_SHELL = 0x100          # or'ed into the dtype of fh_create_ex: the multi-device (RCCL) form even for a single device
@@ -45,12 +52,14 @@ STOP_RULES = ("residual", "norm_residual", "ratio_residual", "hybrid_residual") 
 
 class RunOpts(C.Structure):                 # fh_run_opts
     _fields_ = [(k, _i32) for k in ("adaptive", "accelerate", "backtrack", "restart", "evaluate_objective", "stop_rule", "window",
-                                    "max_backtracks")] + [("stepsize_shrink", _dbl), ("tolerance", _dbl)]
+                                    "max_backtracks")] + [("stepsize_shrink", _dbl), ("tolerance", _dbl), ("launch_mode", _i32), ("reserved", _i32)]
 
 
 class RunState(C.Structure):                # fh_run_state
     _fields_ = [("tau_next", _dbl), ("alpha1", _dbl), ("max_residual", _dbl), ("best_quality", _dbl), ("iteration", _u64), ("backtracks", _u64),
-                ("stopped", _i32), ("reserved", _i32), ("f_window", _dbl * RUN_WINDOW_MAX)]
+                ("stopped", _i32), ("reserved", _i32), ("f_window", _dbl * RUN_WINDOW_MAX),
+                ("spec_cooldown", _i32), ("onepass_backoff", _i32), ("onepass_off_until", C.c_int64),
+                ("onepass_launches", _u64), ("pair_launches", _u64), ("onepass_timeouts", _u64)]
 
 
 
@@ -85,6 +94,8 @@ SIGNATURES = {
     "fh_commit": (_i32, [_ctx, _i32]),
     "fh_run_supported": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_run": (_i32, [_ctx, _i32, C.POINTER(RunOpts), C.POINTER(RunState), _pd, C.POINTER(_i32)]),
+    "fh_iterate": (_i32, [_ctx, _i32, C.POINTER(RunOpts), C.POINTER(RunState), _pd, C.POINTER(_i32)]),
+    "fh_recovered_count": (_i32, [_ctx, _i32, C.POINTER(_u64)]),
     "fh_fused_supported": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_fused_agree": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_coresident_probe": (_i32, [_ctx, _i32, C.POINTER(_i32)]),
@@ -120,9 +131,12 @@ class HipError(RuntimeError):
 
 
 class HipTimeout(HipError):
-    """The one-pass kernel's bounded hand-off spins ran out (scalar word 15 of the launch): the launch itself succeeded and left the
-    solver state untouched, the caller may fall back to K-fwd / K-adj.  The ONLY HipError a solver may recover from: every other
-    non-zero status (device fault, RCCL error, bad state) must propagate."""
+    """A bounded in-launch hand-off ran out: the one-pass kernel's spins (scalar word 15 of the launch: the launch itself succeeded and
+    left the solver state untouched, the caller may fall back to K-fwd / K-adj), or status FH_E_TIMEOUT -- the clipping-level search of the
+    l-infinity prox / l1-ball projection found no level even alone (the step's outputs are NaN; a second failure on the two-launch path
+    propagates out of fasta()).  The ONLY HipError a solver may recover from: every other non-zero status (device fault, RCCL error,
+    bad state) must propagate.  `partial`: history records of the iterations an fh_iterate call completed before it failed."""
+    partial = None
 
 
 def load_library(path=None):
@@ -144,7 +158,7 @@ def load_library(path=None):
 
 def _check(lib, status):
     if status != 0:
-        raise HipError(f"[{status}] " + lib.fh_last_error().decode(errors="replace"))
+        raise (HipTimeout if status == E_TIMEOUT else HipError)(f"[{status}] " + lib.fh_last_error().decode(errors="replace"))
 
 
 def _as_f64(a):
@@ -429,11 +443,37 @@ class HipContext:
 
     def run(self, max_steps, opts, state):
         """Up to `max_steps` FBS iterations in one persistent launch.  `opts`: RunOpts, `state`: RunState (updated in place).
-        Returns the (steps, RUN_HIST) history block: residual, norm_residual, stepsize, f, objective, backtracks, alpha0, became-best."""
+        Returns the (steps, RUN_HIST) history block: residual, norm_residual, stepsize, f, objective, backtracks, alpha0,
+        became-best (+ 2: acceleration restarted).  A grid-barrier timeout of the launch (FH_E_TIMEOUT) is NOT raised: the block then holds
+        the iterations completed before it, `state.stopped == 3`, and context and state are those of the last completed iteration --
+        the caller carries on with `iterate()` / `step()`."""
         hist = np.empty((int(max_steps), RUN_HIST))
         done = _i32(0)
-        self._call("fh_run", int(max_steps), C.byref(opts), C.byref(state), hist.ctypes.data_as(_pd), C.byref(done))
+        status = self.lib.fh_run(self._h, int(max_steps), C.byref(opts), C.byref(state), hist.ctypes.data_as(_pd), C.byref(done))
+        if status != 0 and not (status == E_TIMEOUT and state.stopped == 3):
+            _check(self.lib, status)
         return hist[:done.value]
+
+    def iterate(self, max_steps, opts, state):
+        """Up to `max_steps` FBS iterations driven by the library's host-side loop (fh_iterate, csrc/fh_host_iterate.h): every operator,
+        loss, prox and sharding form; same arguments and history block as run().  If an iteration fails, the exception carries the records
+        of the iterations completed before it as `.partial` (state and context are those of the last completed iteration)."""
+        hist = np.empty((int(max_steps), RUN_HIST))
+        done = _i32(0)
+        status = self.lib.fh_iterate(self._h, int(max_steps), C.byref(opts), C.byref(state), hist.ctypes.data_as(_pd), C.byref(done))
+        if status != 0:
+            try:
+                _check(self.lib, status)
+            except HipError as exc:
+                exc.partial = hist[:done.value]
+                raise
+        return hist[:done.value]
+
+    def recovered_count(self, what):
+        """In-launch timeouts this context got over: RECOVERED_LEVEL_FALLBACK / RECOVERED_LEVEL_FAILED / RECOVERED_RUN_TIMEOUT."""
+        n = _u64(0)
+        self._call("fh_recovered_count", int(what), C.byref(n))
+        return int(n.value)
 
     def commit(self, save_best=False):
         self._call("fh_commit", 1 if save_best else 0)

@@ -110,18 +110,26 @@ class FBSolver:
     def __init__(self, A, loss, prox, x0, adaptive=True, accelerate=False, verbose=True, max_iters=1000,
                  tolerance=1e-5, stop_rule=stopping.hybrid_residual, L=None, tau0=None, backtrack=True,
                  stepsize_shrink=None, window=10, max_backtracks=20, restart=True, evaluate_objective=False,
-                 record_iterates=False, func=None, *, fused="auto", device_iters=0):
+                 record_iterates=False, func=None, *, fused="auto", device_iters="auto", driver=None):
         """Reference options (fasta/__init__.py:42-53) plus two build-only, keyword-only switches:
         fused = "auto" | True | False -- use the one-pass kernel (`HipContext.step` / `step_accel`, csrc/fh_fused.h)
         when the operator shape supports it (with acceleration: dense operator only).  It is speculative: the
         launch assumes the step is accepted; when the backtracking test fails the iteration falls back to
         K-fwd/K-adj (same results).
-        device_iters = K > 0 (opt-in) -- run the loop itself on the device, K iterations per persistent launch (`HipContext.run`,
-        csrc/fh_run.h): backtracking, FISTA, the Barzilai-Borwein rule and the stop rule are decided there, the histories come back
-        in one block.  For short iterations (n <= 7168), where launches and host round trips dominate.  Taken only when nothing
-        needs the host between two iterations -- `stop_rule` is one of the four of fasta/stopping.py, no `func`, no
-        `record_iterates`, `verbose` off -- and the context has a kernel for it; otherwise the per-iteration path runs (same
-        results, `device_steps` stays 0).  `times[i]` within one launch are interpolated between its start and its end."""
+        driver -- who takes the reference's decisions between two launches:
+          "library" (default)  the library's own host-side loop (`HipContext.iterate`, csrc/fh_host_iterate.h): the launches, scalars and
+                     float64 decisions of `step()` below, bit for bit, without the interpreter's 17-19 us per iteration -- for every
+                     operator, prox and sharding form;
+          "device"   the loop itself on the device (`HipContext.run`, csrc/fh_run.h: one persistent launch per call; backtracking, FISTA,
+                     the Barzilai-Borwein rule and the stop rule decided there) where the context has a kernel for it (dense float64,
+                     n <= 6144, separable prox), the library's host-side loop elsewhere and after a launch of it timed out;
+          "python"   this class's `step()` per iteration (Python between all launches: rounds 1-5).
+        device_iters -- iterations per call of the library / device loop: "auto" (calls sized to ~50 ms, at most 256 iterations) or K > 0.
+        Shorthands kept from round 5: `device_iters=K` alone means driver="device", `device_iters=0` means driver="python".
+        The library and device loops are taken only when nothing needs Python between two iterations -- `stop_rule` is one of the four of
+        fasta/stopping.py, no `func`, no `record_iterates`, window <= 64; otherwise `step()` runs (same results).  `verbose` lines are
+        printed after each call from its history records: same text and order as the reference's (:302-306), in bursts.  `times[i]`
+        within one call are interpolated between its start and its end."""
         self.A, self.loss, self.prox = A, loss, prox
         self.fused_opt = fused
         self.ctx = A.ctx
@@ -136,8 +144,17 @@ class FBSolver:
         self.backtrack, self.stepsize_shrink = backtrack, stepsize_shrink
         self.window, self.max_backtracks, self.restart = window, max_backtracks, restart
         self.evaluate_objective, self.record_iterates, self.func = evaluate_objective, record_iterates, func
-        self.device_iters = int(device_iters or 0)
-        self.device_steps = 0                  # iterations that ran inside persistent launches
+        if device_iters is None or device_iters == "auto":
+            device_iters = -1
+        device_iters = int(device_iters)
+        if driver is None:
+            driver = "python" if device_iters == 0 else ("device" if device_iters > 0 else "library")
+        if driver not in ("library", "device", "python"):
+            raise ValueError('driver must be "library", "device" or "python"')
+        self.driver = driver
+        self.device_iters = device_iters if device_iters > 0 else -1        # -1: calls sized by time
+        self.device_steps = 0                  # iterations that ran inside persistent launches (fh_run)
+        self.library_steps = 0                 # iterations driven by the library's host-side loop (fh_iterate)
 
     # ------------------------------------------------------------------------------------------
     def setup(self):
@@ -229,48 +246,90 @@ class FBSolver:
         self.tau_next = tau0
         self.i = 0
         self.done = False
-        self._run_opts = self._device_loop_options() if self.device_iters > 0 else None
+        self._run_opts = self._library_loop_options() if self.driver != "python" else None
+        # fh_run (the loop on the device) only on request and where the context has a kernel for it
+        self._use_run = bool(self._run_opts is not None and self.driver == "device" and self.fused_opt is not False
+                             and hasattr(self.ctx, "run_supported") and self.ctx.run_supported())
+        self._run_backoff, self._run_retry_at = 64, None      # after a grid-barrier timeout of fh_run: iterations on the host-side loop before the next try
+        self._chunk = 8                                       # device_iters = "auto": iterations of the next library call
         return self
 
     # ------------------------------------------------------------------------------------------
-    def _device_loop_options(self):
-        """hip.RunOpts when the loop can run on the device (see __init__), else None."""
+    def _library_loop_options(self):
+        """hip.RunOpts when the library can drive the loop (fh_run / fh_iterate: see __init__), else None."""
         rules = {getattr(stopping, name): k for k, name in enumerate(hip.STOP_RULES)}
         c = self.ctx
-        if (self.stop_rule not in rules or self.func or self.record_iterates or self.verbose or not hasattr(c, "run_supported")
-                or not 1 <= int(self.window) <= hip.RUN_WINDOW_MAX or self.fused_opt is False or not c.run_supported()):
+        if (self.stop_rule not in rules or self.func or self.record_iterates or not hasattr(c, "iterate")
+                or not 1 <= int(self.window) <= hip.RUN_WINDOW_MAX):
             return None
         o = hip.RunOpts()
         o.adaptive, o.accelerate, o.backtrack, o.restart = int(bool(self.adaptive)), int(bool(self.accelerate)), int(bool(self.backtrack)), int(bool(self.restart))
         o.evaluate_objective, o.stop_rule, o.window, o.max_backtracks = int(bool(self.evaluate_objective)), rules[self.stop_rule], int(self.window), int(self.max_backtracks)
         o.stepsize_shrink = float(self.stepsize_shrink) if self.backtrack else 1.0
         o.tolerance = float(self.tolerance)
+        o.launch_mode = hip.LAUNCH_MODES[self.mode]
         return o
 
-    def _run_on_device(self):
-        """The loop in persistent launches of `device_iters` iterations each (csrc/fh_run.h), until the stop rule fires or max_iters."""
-        c, st = self.ctx, hip.RunState()
-        while self.i < self.max_iters and not self.done:
-            i = self.i
-            st.tau_next, st.alpha1, st.max_residual, st.best_quality = self.tau_next, self.alpha1, self.max_residual, self.best_quality
-            st.iteration, st.backtracks, st.stopped = i, self.total_backtracks, 0
-            lo = max(i - self.window + 1, 0)
-            for j in range(lo, i + 1):
-                st.f_window[j % hip.RUN_WINDOW_MAX] = self.f_hist[j]
-            t0 = time()
-            h = c.run(min(self.device_iters, self.max_iters - i), self._run_opts, st)
-            t1 = time()
-            k = len(h)
-            self.residuals[i:i + k], self.norm_residuals[i:i + k], self.stepsizes[i:i + k] = h[:, 0], h[:, 1], h[:, 2]
-            self.f_hist[i + 1:i + k + 1] = h[:, 3]
-            if self.evaluate_objective:
-                self.objectives[i + 1:i + k + 1] = h[:, 4]
-            self.times[i:i + k] = t0 + (t1 - t0) * np.arange(k) / max(k, 1)         # (one launch: the iterations' stamps are interpolated)
-            self.tau_next, self.alpha1, self.max_residual, self.best_quality = st.tau_next, st.alpha1, st.max_residual, st.best_quality
-            self.total_backtracks = int(st.backtracks)
-            self.i = int(st.iteration)
+    def _library_call(self, upto=None):
+        """One call of the library's loop: fh_run (persistent launch) where enabled, else fh_iterate; adopts its histories and state.
+        upto: do not go past this iteration index."""
+        c, st, o = self.ctx, hip.RunState(), self._run_opts
+        i = self.i
+        st.tau_next, st.alpha1, st.max_residual, st.best_quality = self.tau_next, self.alpha1, self.max_residual, self.best_quality
+        st.iteration, st.backtracks, st.stopped = i, self.total_backtracks, 0
+        lo = max(i - self.window + 1, 0)
+        for j in range(lo, i + 1):
+            st.f_window[j % hip.RUN_WINDOW_MAX] = self.f_hist[j]
+        if self._run_retry_at is not None and i >= self._run_retry_at:
+            self._use_run, self._run_retry_at = True, None
+        K = self.device_iters if self.device_iters > 0 else self._chunk
+        K = min(K, (self.max_iters if upto is None else min(upto, self.max_iters)) - i)
+        on_device = self._use_run
+        if not on_device:       # the launch policy's memory travels with the state (csrc/fh_host_iterate.h)
+            fused_mode = self.mode in ("always", "speculative")
+            o.launch_mode = hip.LAUNCH_MODES[self.mode] if (self.use_fused or self._fused_retry_at is not None or not fused_mode) else hip.LAUNCH_SEPARATE
+            st.spec_cooldown, st.onepass_backoff = self._spec_cooldown, self._fused_backoff
+            st.onepass_off_until = -1 if (self.use_fused or self._fused_retry_at is None) else self._fused_retry_at
+        t0 = time()
+        h = c.run(K, o, st) if on_device else c.iterate(K, o, st)
+        t1 = time()
+        k = len(h)
+        self.residuals[i:i + k], self.norm_residuals[i:i + k], self.stepsizes[i:i + k] = h[:, 0], h[:, 1], h[:, 2]
+        self.f_hist[i + 1:i + k + 1] = h[:, 3]
+        if self.evaluate_objective:
+            self.objectives[i + 1:i + k + 1] = h[:, 4]
+        self.times[i:i + k] = t0 + (t1 - t0) * np.arange(k) / max(k, 1)         # (one call: the iterations' stamps are interpolated)
+        self.tau_next, self.alpha1, self.max_residual, self.best_quality = st.tau_next, st.alpha1, st.max_residual, st.best_quality
+        self.total_backtracks = int(st.backtracks)
+        self.i = int(st.iteration)
+        if on_device:
             self.device_steps += k
-            self.done = bool(st.stopped) or self.i >= self.max_iters
+            if st.stopped == 3:        # a grid barrier of the persistent launch timed out: state and context are those of the last completed iteration
+                warnings.warn(f"device-side loop (fh_run) timed out after {k} iterations of its launch (workgroups not co-resident?): "
+                              f"continuing on the library's host-side loop for the next {self._run_backoff} iterations")
+                self._use_run, self._run_retry_at = False, self.i + self._run_backoff
+                self._run_backoff *= 2
+        else:
+            self.library_steps += k
+            self.fused_steps += int(st.onepass_launches)
+            self.pair_steps += int(st.pair_launches)
+            self._spec_cooldown, self._fused_backoff = int(st.spec_cooldown), int(st.onepass_backoff)
+            if st.onepass_timeouts:
+                warnings.warn(f"fused one-pass kernel disabled until iteration {int(st.onepass_off_until)}: its team hand-off timed out "
+                              f"{int(st.onepass_timeouts)} time(s) in this call (workgroups not co-resident?); K-fwd / K-adj meanwhile")
+            if fused_mode:
+                self.use_fused = st.onepass_off_until < 0 and o.launch_mode != hip.LAUNCH_SEPARATE
+                self._fused_retry_at = None if st.onepass_off_until < 0 else int(st.onepass_off_until)
+            if self.device_iters < 0 and k == K and t1 > t0:        # "auto": size the next call to ~50 ms, 1..256 iterations
+                self._chunk = int(min(256, max(1, 0.05 * k / (t1 - t0))))
+        if self.verbose:                                            # :302-306, from the records: same text, same order, per call
+            for q in range(k):
+                if int(h[q, 7]) & 2:
+                    print("Restarted acceleration.")
+                print("[{:<6}]\t{:e}\t{:e}\t{:e}\t{:6}\t{:e}".format(
+                    i + q, self.residuals[i + q], self.stepsizes[i + q], h[q, 6] if self.accelerate else 0.0,
+                    int(h[q, 5]) if self.backtrack else 0, self.objectives[i + q] if self.evaluate_objective else 0))
+        self.done = st.stopped == 1 or self.i >= self.max_iters
 
     def _forward(self, tau, one_pass):
         """(fwd scalars, adj scalars or None): the one-pass kernel when enabled and asked for, else K-fwd alone."""
@@ -393,15 +452,27 @@ class FBSolver:
                                         self.tolerance)) or self.i >= self.max_iters
         return self.done
 
+    def advance(self, k):
+        """Up to k more iterations, by whoever drives this solve (the library's loop in calls that end at iteration i + k, else `step()`):
+        what `run()` does, in instalments -- bench.py times exactly K iterations with it.  Returns True once the solve has ended."""
+        target = min(self.i + int(k), self.max_iters)
+        with np.errstate(all="ignore"):
+            while self.i < target and not self.done:
+                if self._run_opts is not None:
+                    self._library_call(upto=target)
+                else:
+                    self.step()
+        return self.done
+
     def run(self):
         with warnings.catch_warnings():
             # the reference relies on float64 inf/nan semantics (e.g. 0/0 in the BB rule once converged)
             warnings.simplefilter("ignore", RuntimeWarning)
             with np.errstate(all="ignore"):
-                if self._run_opts is not None:
-                    self._run_on_device()
                 while self.i < self.max_iters and not self.done:
-                    if self.step():
+                    if self._run_opts is not None:
+                        self._library_call()
+                    elif self.step():
                         break
         return self.result()
 
@@ -410,7 +481,8 @@ class FBSolver:
         solution = self.ctx.get_vector(hip.VEC_BEST, self.n).reshape(self.shape)
         conv = Convergence(self.residuals, self.norm_residuals, self.stepsizes, self.total_backtracks, self.times,
                            self.i, solution, self.objectives, self.iterates, self.function_hist)
-        conv.device_steps = self.device_steps         # (build-only diagnostic: iterations that ran inside persistent launches, `device_iters`)
+        conv.device_steps = self.device_steps         # (build-only diagnostics: iterations that ran inside persistent launches -- fh_run --
+        conv.library_steps = self.library_steps       #  and iterations driven by the library's host-side loop -- fh_iterate)
         return conv
 
 
@@ -421,7 +493,9 @@ def fasta(A, *operands, backend="auto", **options):
                            host loop for operands that cannot run in a kernel (closures, callable pair, None, host LinearMap);
                 "hip"   -- device loop or TypeError;   "numpy" -- generic host loop (operands are called as given);
       fused   = "auto" | True | False -- one-pass kernel policy of the device loop (see FBSolver);
-      device_iters = K -- opt-in: the loop itself on the device, K iterations per persistent launch (see FBSolver)."""
+      driver  = "library" | "device" | "python", device_iters = "auto" | K -- who takes the decisions between two launches: the library's
+                host-side loop (default), the loop itself on the device where there is a kernel for it, or Python per iteration; and how
+                many iterations one call of the first two runs (see FBSolver)."""
     if len(operands) == 6:
         At, f, gradf, g, proxg, x0 = operands
     elif len(operands) == 5:
@@ -438,6 +512,7 @@ def fasta(A, *operands, backend="auto", **options):
         from .generic import HostFBS, host_map
         options.pop("fused", None)                                      # device-loop policies, meaningless on the host
         options.pop("device_iters", None)
+        options.pop("driver", None)
         x0 = np.asarray(x0)
         return HostFBS(host_map(A, At, x0), f, gradf, g, proxg, x0, **options).setup().run()
     x0 = np.asarray(x0, dtype=np.float64)

@@ -32,6 +32,10 @@ typedef struct fh_ctx fh_ctx;
 #define FH_E_ARG      10001   /* bad argument / shape mismatch                      */
 #define FH_E_STATE    10002   /* call out of order (e.g. fh_fwd before fh_set_*)     */
 #define FH_E_RCCL     10003   /* librccl could not be loaded / symbol missing        */
+#define FH_E_TIMEOUT  10004   /* a bounded in-launch hand-off ran out (workgroups not co-resident?) and no fall-back inside the library
+                                 could finish the call: the clipping-level search of FH_PROX_LINF / FH_PROX_L1BALL (its outputs are NaN,
+                                 never a finite wrong prox), or a grid barrier of fh_run's persistent launch (the state of the last
+                                 completed iteration is adopted and the completed history returned: continue with fh_iterate / fh_step) */
 
 /* prox operators g(x) <-> proxg(x, t)                                                   */
 enum fh_prox_kind {
@@ -104,6 +108,9 @@ enum fh_tuning_key {
                                 cache lines share an L2 (0 = auto = 1 = on, 2 = off: plain blockIdx order)                    */
   /* keys 13-15 (occupancy limiter, LDS-DMA trip ring, persistent chunk walk of the stencil sweep: measured flat twice,
      profiles/r04_tune_tv.txt) are only present in -DFH_EXPERIMENTAL builds (csrc/fh_experimental.h); FH_E_ARG otherwise        */
+  FH_TUNE_RUN_MAX_N = 17,    /* fh_run: the widest row (columns) the device-side loop is offered for (fh_run_supported); 0 = the measured
+                                default 6144 (beyond it one launch per iteration issued by fh_iterate is as fast), at most 7168 = the widest
+                                row it has a kernel for                                                                             */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
                                 reports).  The co-residency probe then asks for that many.  Lets several one-pass grids run side by side
                                 on one device: two solves at once, partitioned devices, ranks of a row-sharded run that share a GPU
@@ -250,24 +257,56 @@ int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* sca
  *   state   in/out, carried from call to call: after fh_init / fh_setup set tau_next = tau0, alpha1 = 1, max_residual = -inf,
  *           best_quality = +inf, iteration = backtracks = 0, f_window[0] = f(x0) (f_window[j % 64] holds f_hist[j]; window <= 64)
  *   history max_steps records of FH_RUN_HIST doubles: residual, norm_residual, stepsize, f_hist[i+1], objective, backtracks of the
- *           iteration, alpha0, 1 if the iterate became the best one
+ *           iteration, alpha0, 1 if the iterate became the best one (+ 2 if the acceleration was restarted, :231-233)
  *   steps_done  iterations executed (fewer than max_steps when the stop rule fired: state->stopped = 1)
- * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 7168 on a
+ * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 6144 -- FH_TUNE_RUN_MAX_N -- on a
  * single-device context, a scalar-separable prox without level search, every CU free for one resident workgroup).                 */
 #define FH_RUN_HIST 8
 #define FH_RUN_WINDOW_MAX 64
+/* how fh_iterate's forward launches reach the device (fh_run ignores it).  The caller settles it once per solve -- over the ranks of a
+ * row-sharded run with fh_fused_agree -- from fh_fused_agree's verdict: 1 / 2 -> ALWAYS, 3 -> SPECULATIVE, else PAIR (small dense
+ * operator, no acceleration) or SEPARATE.  A policy changes which launches produce the results, never the results.                    */
+enum fh_launch_mode {
+  FH_LAUNCH_SEPARATE = 0,            /* fh_fwd, decide, fh_adj                                                                      */
+  FH_LAUNCH_ONEPASS_ALWAYS = 1,      /* fh_step / fh_step_accel for every launch of the loop, backtracking retries included          */
+  FH_LAUNCH_ONEPASS_SPECULATIVE = 2, /* fh_step / fh_step_accel, except for 8 iterations after a backtrack and in the retries         */
+  FH_LAUNCH_PAIR = 3                 /* fh_fwd_adj (one synchronisation), same exceptions; no acceleration                            */
+};
 typedef struct fh_run_opts {
   int adaptive, accelerate, backtrack, restart, evaluate_objective, stop_rule, window, max_backtracks;
   double stepsize_shrink, tolerance;
+  int launch_mode;                   /* fh_iterate only: enum fh_launch_mode                                                        */
+  int reserved;
 } fh_run_opts;
 typedef struct fh_run_state {
   double tau_next, alpha1, max_residual, best_quality;
   uint64_t iteration, backtracks;
-  int stopped, reserved;
+  int stopped, reserved;             /* stopped: 0 = ran out of steps, 1 = the stop rule fired, 3 = fh_run's launch timed out (FH_E_TIMEOUT) */
   double f_window[FH_RUN_WINDOW_MAX];
+  /* fh_iterate only -- the launch policy's memory, carried from call to call like the rest (set spec_cooldown = 0, onepass_off_until = -1,
+   * onepass_backoff = 64 and the three counters to 0 before the first call):                                                       */
+  int spec_cooldown;                 /* iterations left before the one-pass kernel / the pair is speculated on again after a backtrack */
+  int onepass_backoff;               /* iterations to stay off the one-pass kernel after its NEXT hand-off timeout (doubles per failure) */
+  int64_t onepass_off_until;         /* -1, or the iteration from which the one-pass kernel is tried again after a hand-off timeout    */
+  uint64_t onepass_launches, pair_launches, onepass_timeouts;   /* totals: one-pass launches that delivered, pairs, hand-off timeouts  */
 } fh_run_state;
 int fh_run_supported(fh_ctx* ctx, int* yes);
+/* After a grid-barrier timeout of the persistent launch (workgroups not co-resident) fh_run returns FH_E_TIMEOUT with state->stopped = 3:
+ * the context and `state` are those of the last COMPLETED iteration (state->tau_next = the step the interrupted iteration started with),
+ * `history` / `steps_done` describe the completed ones -- the caller continues with fh_iterate or fh_step.  Any other failure: FH_E_STATE. */
 int fh_run(fh_ctx* ctx, int max_steps, const fh_run_opts* opts, fh_run_state* state, double* history, int* steps_done);
+/* The same loop driven from the HOST side of the library (csrc/fh_host_iterate.h), for EVERY operator, loss, prox and sharding form the
+ * step entry points serve -- a dense matrix of any width, the level-search prox kinds, the stencil, float32 storage, row blocks in this
+ * process, a rank of a row-sharded run (every rank calls it with the same arguments).  Per iteration it issues what the Python driver of
+ * round 1-5 issued (fh_step / fh_step_accel / fh_fwd / fh_adj / fh_fwd_adj by opts->launch_mode, then fh_commit), synchronises once and takes
+ * the reference's decisions (fasta/__init__.py:195-217, :220-238, :253-270, :272-300; fasta/stopping.py:6-51) in float64 exactly as that
+ * driver does -- results are bit-identical to it -- without the 17-19 us of interpreter time per iteration.  Arguments, state, history
+ * records (record[7] = 1 if the iterate became the best one, + 2 if the acceleration was restarted) and steps_done as fh_run.  On an
+ * error the completed iterations stay committed and are reported (state, history, steps_done); the failed one has changed nothing.   */
+int fh_iterate(fh_ctx* ctx, int max_steps, const fh_run_opts* opts, fh_run_state* state, double* history, int* steps_done);
+/* how often this context got over an in-launch timeout by itself: what = 0 clipping-level searches finished by the single-workgroup
+ * fall-back, 1 = searches that found no level (reported as FH_E_TIMEOUT), 2 = fh_run launches that ended in a barrier timeout      */
+int fh_recovered_count(fh_ctx* ctx, int what, uint64_t* count);
 /* x0 <- x1, g0 <- g1, acceleration history rotates (:176-177, :222-226); save_best != 0 also
  * copies x1 into FH_VEC_BEST (:298-300).                                                         */
 int fh_commit(fh_ctx* ctx, int save_best);

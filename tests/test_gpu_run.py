@@ -47,8 +47,8 @@ def test_golden_parity_with_the_loop_on_the_device(name, K):
     np.testing.assert_allclose(c.solution, z["solution"], rtol=1e-5, atol=1e-9)
 
 
-def _solve(A, b, reg, x0, **opts):
-    op = fa.DenseMatrixMap(A)
+def _solve(A, b, reg, x0, tuning=None, **opts):
+    op = fa.DenseMatrixMap(A, tuning=tuning)
     try:
         ls = fa.LeastSquares(b)
         np.random.seed(5)
@@ -75,8 +75,10 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     xt[rng.permutation(n)[:max(1, n // 50)]] = 1
     b = A @ xt + 0.01 * rng.randn(m)
     opts = dict(tolerance=1e-7, max_iters=120, evaluate_objective=True, **MODES[mode])
+    # (rows wider than 6144 columns are offered to fh_run only on request -- FH_TUNE_RUN_MAX_N: there the per-iteration launches are as fast)
+    tuning = {hip.TUNE_RUN_MAX_N: 7168} if n > 6144 else None
     host = _solve(A, b, fa.Shrink(0.02), np.zeros(n), fused=True, **opts)
-    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=16, **opts)
+    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), tuning=tuning, device_iters=16, **opts)
     assert host.device_steps == 0 and dev.device_steps == dev.iteration_count
     k = host.iteration_count
     assert dev.iteration_count == k and dev.backtracks == host.backtracks
@@ -153,7 +155,9 @@ def test_options_that_need_the_host_between_iterations_keep_the_per_iteration_pa
         assert got.device_steps == 0 and got.iteration_count == ref.iteration_count
         assert np.array_equal(got.residuals, ref.residuals) and np.array_equal(got.solution, ref.solution)
     wide = _solve(rng.randn(50, 9000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(9000), device_iters=8, max_iters=10)     # n > 7168: no kernel
-    assert wide.device_steps == 0 and wide.iteration_count == 10
+    assert wide.device_steps == 0 and wide.library_steps == wide.iteration_count == 10
+    beyond = _solve(rng.randn(50, 7000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(7000), device_iters=8, max_iters=10)   # n > 6144: a kernel, but not offered by default
+    assert beyond.device_steps == 0 and beyond.library_steps == 10
 
 
 def test_operators_without_a_device_loop_keep_the_per_iteration_path():
