@@ -101,10 +101,8 @@ static int create_body(fh_ctx* c, int device, hipStream_t shared_stream = nullpt
   HIP_TRY(hipHostMalloc((void**)&c->hscal, (FH_NSCALARS + 16) * sizeof(double), hipHostMallocMapped));
   memset(c->hscal, 0, (FH_NSCALARS + 16) * sizeof(double));
   HIP_TRY(hipHostGetDevicePointer((void**)&c->hscal_dev, c->hscal, 0));
-  for (int k = 0; k < FH_NKERNELS; ++k) {
-    HIP_TRY(hipEventCreate(&c->ev[k][0]));
-    HIP_TRY(hipEventCreate(&c->ev[k][1]));
-  }
+  for (int k = 0; k < FH_NKERNELS; ++k)
+    for (int q = 0; q < 4; ++q) HIP_TRY(hipEventCreate(&c->ev[k][q / 2][q % 2]));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -125,7 +123,7 @@ static int create_one(int device, hipStream_t shared_stream, fh_ctx** out) {
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(FH_E_ARG, "fh_create: device %d out of range (have %d)", device, ndev);
   fh_ctx* c = new fh_ctx();
-  for (int k = 0; k < FH_NKERNELS; ++k) c->ev[k][0] = c->ev[k][1] = nullptr;
+  for (int k = 0; k < FH_NKERNELS; ++k) for (int q = 0; q < 4; ++q) c->ev[k][q / 2][q % 2] = nullptr;
   const int rc = create_body(c, device, shared_stream);
   if (rc != 0) return create_failed(c, rc);          // release whatever was created (the error text is already set)
   *out = c;
@@ -169,7 +167,7 @@ extern "C" int fh_create_ex(int ndev, const int* dev_ids, int dtype, fh_ctx** ou
   const bool one_device = equal;
   const bool use_rccl = distinct || rccl_shell;
   fh_ctx* shell = new fh_ctx();
-  for (int k = 0; k < FH_NKERNELS; ++k) shell->ev[k][0] = shell->ev[k][1] = nullptr;
+  for (int k = 0; k < FH_NKERNELS; ++k) for (int q = 0; q < 4; ++q) shell->ev[k][q / 2][q % 2] = nullptr;
   shell->device = dev_ids[0];
   shell->emulated = !use_rccl;
   shell->f32 = dtype == FH_DTYPE_F32_STORAGE ? 1 : 0;
@@ -220,7 +218,7 @@ extern "C" int fh_destroy(fh_ctx* c) {
   if (c->counters) (void)hipFree(c->counters);
   if (c->dscal) (void)hipFree(c->dscal);
   if (c->hscal) (void)hipHostFree(c->hscal);
-  for (int k = 0; k < FH_NKERNELS; ++k) { if (c->ev[k][0]) (void)hipEventDestroy(c->ev[k][0]); if (c->ev[k][1]) (void)hipEventDestroy(c->ev[k][1]); }
+  for (int k = 0; k < FH_NKERNELS; ++k) for (int q = 0; q < 4; ++q) if (c->ev[k][q / 2][q % 2]) (void)hipEventDestroy(c->ev[k][q / 2][q % 2]);
   if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -306,6 +304,8 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
       if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->slots_sig = 0; }
       return 0;
+    case FH_TUNE_SEQ_POLL:
+      c->seq_poll = value ? 1 : 0; return 0;
     case FH_TUNE_RUN_MAX_N:
       if (value < 0 || value > 7168) return fail(FH_E_ARG, "RUN_MAX_N must be in [0, 7168] (0 = the measured default; 7168 = the widest row fh_run has a kernel for)");
       c->run_max_n = (int)value; return 0;
@@ -1321,6 +1321,9 @@ extern "C" int fh_timing_get(fh_ctx* c, int k, double* total_ms, uint64_t* launc
     if (launches) *launches = c->host_issue_calls;
     return 0;
   }
+  // (event pairs recorded since the last stream synchronisation are read now: a step that was waited for by its sequence number leaves its pair pending)
+  if (c->shards.empty()) { (void)hipSetDevice(c->device); t_harvest(c, k, 0, true); t_harvest(c, k, 1, true); }
+  for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); t_harvest(s, k, 0, true); t_harvest(s, k, 1, true); }
   double ms = c->tot_ms[k];
   uint64_t cnt = c->launches[k];
   if (c->emulated && !c->shards.empty()) {       // one block sampled, scaled (fh_timing_enable); the sum over the blocks runs once
@@ -1338,7 +1341,7 @@ extern "C" int fh_timing_get(fh_ctx* c, int k, double* total_ms, uint64_t* launc
 extern "C" int fh_timing_reset(fh_ctx* c) {
   if (!c) return fail(FH_E_ARG, "null context");
   for (fh_ctx* s : c->shards) FH_TRY(fh_timing_reset(s));
-  for (int k = 0; k < FH_NKERNELS; ++k) { c->tot_ms[k] = 0; c->launches[k] = 0; c->ev_pending[k] = false; }
+  for (int k = 0; k < FH_NKERNELS; ++k) { c->tot_ms[k] = 0; c->launches[k] = 0; c->ev_pending[k][0] = c->ev_pending[k][1] = false; }
   c->host_issue_ms = 0.0; c->host_issue_calls = 0; c->issue_open = false;
   return 0;
 }
@@ -1349,9 +1352,13 @@ extern "C" int fh_timing_reset(fh_ctx* c) {
 extern "C" int fh_timing_overlap(fh_ctx* a, fh_ctx* b, int k, double* a_ms, double* b_ms, double* overlap_ms) {
   if (!a || !b || k < 0 || k >= FH_NKERNELS || k == FH_K_HOST_ISSUE) return fail(FH_E_ARG, "fh_timing_overlap: bad argument");
   if (!a->shards.empty() || !b->shards.empty() || a->device != b->device) return fail(FH_E_ARG, "fh_timing_overlap takes two plain contexts on one device");
-  if (!a->launches[k] || !b->launches[k] || a->ev_pending[k] || b->ev_pending[k] || a->pending_step || b->pending_step)
-    return fail(FH_E_STATE, "fh_timing_overlap: both contexts need a completed, timed launch of kernel %d", k);
   FH_TRY(use_device(a));
+  // the LATEST recorded pair of each context (its launch has been waited for; the pair itself may not have been read yet)
+  const int sa = a->ev_cur[k], sb = b->ev_cur[k];
+  if (a->pending_step || b->pending_step || (!a->launches[k] && !a->ev_pending[k][sa]) || (!b->launches[k] && !b->ev_pending[k][sb]))
+    return fail(FH_E_STATE, "fh_timing_overlap: both contexts need a completed, timed launch of kernel %d", k);
+  HIP_TRY(hipEventSynchronize(a->ev[k][sa][1]));
+  HIP_TRY(hipEventSynchronize(b->ev[k][sb][1]));
   // signed time from event e1 to event e2 (whichever way round the runtime is willing to subtract them)
   auto between = [](hipEvent_t e1, hipEvent_t e2, float* ms) -> hipError_t {
     hipError_t r = hipEventElapsedTime(ms, e1, e2);
@@ -1359,9 +1366,9 @@ extern "C" int fh_timing_overlap(fh_ctx* a, fh_ctx* b, int k, double* a_ms, doub
     return r;
   };
   float da = 0.f, db0 = 0.f, db1 = 0.f;               // everything relative to the start of a's launch
-  HIP_TRY(between(a->ev[k][0], a->ev[k][1], &da));
-  HIP_TRY(between(a->ev[k][0], b->ev[k][0], &db0));
-  HIP_TRY(between(a->ev[k][0], b->ev[k][1], &db1));
+  HIP_TRY(between(a->ev[k][sa][0], a->ev[k][sa][1], &da));
+  HIP_TRY(between(a->ev[k][sa][0], b->ev[k][sb][0], &db0));
+  HIP_TRY(between(a->ev[k][sa][0], b->ev[k][sb][1], &db1));
   if (a_ms) *a_ms = da;
   if (b_ms) *b_ms = db1 - db0;
   if (overlap_ms) *overlap_ms = std::min(da, db1) - std::max(0.f, db0);

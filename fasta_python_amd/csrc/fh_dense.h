@@ -179,6 +179,7 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) p.out[k] = v[k];
       p.out[S_ALPHA] = level;
+      publish_seq(p.out, p.px.seq);
       __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -201,6 +202,7 @@ struct AdjP {
   int accel;            // extrapolate z and x with `coef`
   double coef;
   int mode;             // 0 = FBS (BB epilogue), 1 = plain gradient (g1 only), 2 = sharded (g1 partial + local fsq only)
+  unsigned seq;         // (in the struct's padding) != 0: published behind the scalar block by the finaliser (fh_device.h:publish_seq)
   double tau;
   const double* x0; const double* xp; const double* xacc0; const double* xhat;
   double* x1;           // extrapolated iterate (accel only; else == xp and not written)
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   if (tid == 0) {
     p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
     p.out[S_GSUM_ADJ] = w[3]; p.out[S_GMAX_ADJ] = w[4]; p.out[S_FSQ_ADJ] = w[5];
+    publish_seq(p.out, p.seq);
     __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

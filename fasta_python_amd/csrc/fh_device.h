@@ -50,6 +50,7 @@ enum { PX_PLAIN = -1, PX_IDENTITY = 0, PX_SHRINK = 1, PX_NONNEG = 2, PX_LINF = 3
 
 struct ProxP {
   int kind;
+  unsigned seq;        // (in the struct's padding) != 0: the launch's finaliser publishes this number behind the scalar block (publish_seq below)
   double thr;          // shrink: tau*mu (rounded on the host exactly like `t*self.mu`)
   double lo, hi;       // box
   const double* level; // LINF / L1BALL: device scalar holding the clipping level alpha
@@ -329,6 +330,22 @@ __device__ __forceinline__ bool arrive_last2(unsigned* base, volatile unsigned* 
   }
   __syncthreads();
   return *flag != 0u;
+}
+
+// ---- "the scalars are there" without waiting for the end of the launch (round 6) -----------------------------------------------------------
+// A single-GPU launch writes its FH_S_* block straight into host-mapped memory.  The host used to learn that it may read it from
+// hipStreamSynchronize -- i.e. from the completion signal of the whole launch, 14.8 us after its last instruction for an empty kernel; a
+// word the launch itself writes behind the block and the host spins on arrives after 10.0 (scripts/probes/bench_mem/launchgap.hip,
+// profiles/r06_launchgap.txt): 4-5 us off EVERY iteration of every operator.  The finalising thread calls this after its last store to the
+// block: its stores to host memory are acknowledged (vmcnt), then the sequence number follows as one system-scope store.  No cache
+// write-back is involved: the block is uncached host memory, and what the launch wrote to device memory is read only by later launches on
+// the same stream (or by copies ordered behind the launch's completion, as before).
+#define FH_SEQ_SLOT 28                       // in doubles from the start of the scalar block (FH_NSCALARS + 16 doubles are allocated)
+__device__ __forceinline__ void publish_seq(double* out, unsigned seq) {
+  if (seq) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(reinterpret_cast<unsigned*>(out + FH_SEQ_SLOT), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // K doubles per workgroup, all held by thread 0 (the usual case after block_reduce)

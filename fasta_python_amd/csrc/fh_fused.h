@@ -647,6 +647,7 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
       const double timed_out = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
       p.out[15] = timed_out;
       if (p.pack) { p.pack[0] = a[0]; p.pack[1] = timed_out; p.pack[2] = p.accel ? a[7] : a[0]; }
+      publish_seq(p.out, p.px.seq);
       // leave the counters zero for the next launch (every workgroup is past the grid barrier and has taken its final ticket)
       __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -183,8 +183,15 @@ struct fh_ctx {
   int slots_parity = 0;
   // timing
   bool timing = false;
-  hipEvent_t ev[FH_NKERNELS][2];
-  bool ev_pending[FH_NKERNELS] = {};
+  // two event pairs per kernel id, used alternately: a pair is read (hipEventElapsedTime) when it is about to be re-recorded, i.e. two launches
+  // after its own -- long complete, so the harvest never waits even when the host did not synchronise the stream in between (seq_wait below)
+  hipEvent_t ev[FH_NKERNELS][2][2];
+  bool ev_pending[FH_NKERNELS][2] = {};
+  int ev_cur[FH_NKERNELS] = {};
+  // "the scalars are there" by sequence number (fh_device.h:publish_seq): the launcher of a kernel whose finaliser publishes one sets seq_wait
+  // to the number it passed; collect_scalars then spins on the word behind the mapped scalar block instead of synchronising the stream
+  unsigned seq = 0, seq_wait = 0;
+  int seq_poll = 1;          // FH_TUNE_SEQ_POLL: 0 = always hipStreamSynchronize (A/B)
   // FH_K_HOST_ISSUE: host time of a one-pass dense step from its entry to the start of its final synchronisation
   bool timing_skip_kernels = false;
   double host_issue_ms = 0.0; uint64_t host_issue_calls = 0;
@@ -321,29 +328,71 @@ static int ensure_ws(fh_ctx* c, size_t bytes) {
 
 // ---- timing helpers ------------------------------------------------------------------------------
 // (timing_skip_kernels: a block of a same-device multi-block context that is not the sampled one -- fh_timing_enable)
+static inline bool t_on(fh_ctx* c, int k) { return c->timing && !(c->timing_skip_kernels && k != FH_K_COMM); }
+// read a recorded pair; wait = true: wait for its stop event first (only fh_timing_get and a pair reused before it completed need that)
+static void t_harvest(fh_ctx* c, int k, int s, bool wait) {
+  if (!c->ev_pending[k][s]) return;
+  float ms = 0.f;
+  hipError_t e = hipEventElapsedTime(&ms, c->ev[k][s][0], c->ev[k][s][1]);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    if (!wait) return;
+    (void)hipEventSynchronize(c->ev[k][s][1]);
+    e = hipEventElapsedTime(&ms, c->ev[k][s][0], c->ev[k][s][1]);
+  }
+  if (e == hipSuccess) { c->tot_ms[k] += ms; c->launches[k] += 1; }
+  else (void)hipGetLastError();
+  c->ev_pending[k][s] = false;
+}
 static inline void t_begin(fh_ctx* c, int k) {
-  if (c->timing && !(c->timing_skip_kernels && k != FH_K_COMM)) { (void)hipEventRecord(c->ev[k][0], c->stream); }
+  c->seq_wait = 0;                   // (every launcher passes here: only the LAST launch before collect_scalars may offer a sequence number)
+  if (t_on(c, k)) {
+    const int s = c->ev_cur[k] ^ 1;
+    t_harvest(c, k, s, true);
+    c->ev_cur[k] = s;
+    (void)hipEventRecord(c->ev[k][s][0], c->stream);
+  }
 }
 static inline void t_end(fh_ctx* c, int k) {
-  if (c->timing && !(c->timing_skip_kernels && k != FH_K_COMM)) { (void)hipEventRecord(c->ev[k][1], c->stream); c->ev_pending[k] = true; }
+  if (t_on(c, k)) { (void)hipEventRecord(c->ev[k][c->ev_cur[k]][1], c->stream); c->ev_pending[k][c->ev_cur[k]] = true; }
+}
+// the sequence number the next launch's finaliser is to publish (0 = none: the caller will synchronise the stream)
+static inline unsigned seq_offer(fh_ctx* c) {
+  if (!c->seq_poll || !c->shards.empty() || c->comm != nullptr || c->owner != nullptr) return 0u;
+  c->seq = c->seq + 1u ? c->seq + 1u : 1u;
+  c->seq_wait = c->seq;
+  return c->seq;
 }
 static int finish(fh_ctx* c) {   // synchronise the stream and harvest pending event pairs
   if (!c->shards.empty()) {        // shell: all shards (an emulated group shares one stream; its first shard's sync covers the rest)
     for (fh_ctx* s : c->shards) { HIP_TRY(hipSetDevice(s->device)); FH_TRY(finish(s)); }
     return 0;
   }
+  c->seq_wait = 0;
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->timing) {
-    for (int k = 0; k < FH_NKERNELS; ++k) {
-      if (!c->ev_pending[k]) continue;
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, c->ev[k][0], c->ev[k][1]));
-      c->tot_ms[k] += ms;
-      c->launches[k] += 1;
-      c->ev_pending[k] = false;
-    }
+    for (int k = 0; k < FH_NKERNELS; ++k) { t_harvest(c, k, 0, true); t_harvest(c, k, 1, true); }
   }
   return 0;
+}
+// Wait until the scalar block of the latest launch is on the host: by its sequence number when the launch publishes one (the host
+// returns ~5 us before the launch's completion signal would have let it; what follows on the stream is ordered behind the launch as
+// always), else -- or if the stream goes idle without the number having arrived, which a healthy launch cannot do -- by synchronising.
+static int wait_scalars(fh_ctx* c) {
+  const unsigned want = c->seq_wait;
+  if (!want) return finish(c);
+  c->seq_wait = 0;
+  volatile unsigned* word = reinterpret_cast<volatile unsigned*>(c->hscal + FH_SEQ_SLOT);
+  for (unsigned spins = 1;; ++spins) {
+    if (*word == want) return 0;
+    if ((spins & 0xFFFu) == 0u) {                            // every few tens of microseconds: is the stream still busy at all?
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) { if (*word == want) return 0; return finish(c); }     // (idle: the block is as complete as it will get)
+      if (q != hipErrorNotReady) return fail((int)q, "hipStreamQuery failed while waiting for a launch: %s", hipGetErrorString(q));
+      (void)hipGetLastError();
+    }
+    __builtin_ia32_pause();
+  }
 }
 
 // Where kernels write the FH_S_* block: straight into the mapped host block on one GPU (no D2H copy, the
@@ -378,7 +427,7 @@ static int issue_scalars(fh_ctx* c) {
   return 0;
 }
 static int collect_scalars(fh_ctx* c, double* scalars) {
-  FH_TRY(finish(c));               // ONE host synchronisation per call (per device of a shell)
+  FH_TRY(c->shards.empty() ? wait_scalars(c) : finish(c));               // ONE host wait per call (per device of a shell)
   // every shard holds the same block: each entry is either a sum over all shards or computed from replicated vectors
   fh_ctx* s0 = shard_of(c, 0);
   if (scalars) memcpy(scalars, s0->hscal, FH_NSCALARS * sizeof(double));

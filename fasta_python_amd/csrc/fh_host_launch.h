@@ -12,6 +12,7 @@ static ProxP make_prox(fh_ctx* c, double tau) {
   px.thr = tau * c->mu;               // `t*self.mu`, examples/sparse_least_squares.py:44
   px.lo = c->lo; px.hi = c->hi;
   px.level = c->dscal + FH_NSCALARS;  // device scalar written by the level search
+  px.seq = 0;
   return px;
 }
 
@@ -64,6 +65,7 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
   p.counter = c->counters + CNT_FWD;
   p.out = scalar_out(c);
   t_begin(c, FH_K_FWD);
+  p.px.seq = seq_offer(c);
   switch (R) {
     case 4: launch_fwd_r<4>(c, p, grid, kind); break;
     case 16: launch_fwd_r<16>(c, p, grid, kind); break;
@@ -119,6 +121,7 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   p.out = scalar_out(c);
   const unsigned grid = p.ncc * p.nslab;
   t_begin(c, FH_K_ADJ);
+  p.seq = io.mode == 0 ? seq_offer(c) : 0u;      // (the plain-gradient / sharded forms are followed by further launches)
   switch (CPT) {
     case 1: launch_adj_c<1>(c, p, grid); break;
     case 4: launch_adj_c<4>(c, p, grid); break;
@@ -462,6 +465,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
     c->slots_parity ^= 1;
   }
+  p.px.seq = io.mode == 0 ? seq_offer(c) : 0u;
   k_fused_dense_entry->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
@@ -694,6 +698,7 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
   p.red = c->ws; p.counter = c->counters + CNT_FWD; p.out = scalar_out(c);
   p.arrive = c->gridbar + 2 * GB_WORDS;
   t_begin(c, FH_K_FUSED);
+  p.seq = seq_offer(c);
   // tunables -> template parameters.  Non-temporal LOADS lose 12 % here (the halo columns and rows are re-read by the neighbouring
   // waves and workgroups through L2), so this sweep only distinguishes non-temporal (default) and plain STORES (FH_TUNE_TV_NT = 3).
   const int nb = c->tv_pipe ? c->tv_pipe : (accel ? 3 : 1);

@@ -939,6 +939,7 @@ struct TvZP {
   int restart;
   int xcd_order;                         // 1 = logical workgroup ids dealt out XCD by XCD (tv_xcd_order)
   uint32_t nchunks;                      // strip_groups * row bands; a smaller grid walks the chunk ids with stride gridDim.x
+  unsigned seq;                          // (in the struct's padding) != 0: published behind the scalar block by the finaliser (fh_device.h:publish_seq)
   double* red; unsigned* counter; double* out;
   unsigned* arrive;                      // GB_WORDS words of the two-level final arrival (fh_device.h:arrive_last2): ~1260 workgroups finish together here
 };
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       p.out[S_FSQ_ADJ] = plain ? a[0] : bq[5];
       p.out[S_ALPHA] = 0.0;
       p.out[15] = 0.0;
+      publish_seq(p.out, p.seq);
     }
   }
   if (tid < GB_GROUPS + 1) __hip_atomic_store(p.arrive + tid * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // leave the arrival counters zero for the next launch

@@ -111,6 +111,8 @@ enum fh_tuning_key {
   FH_TUNE_RUN_MAX_N = 17,    /* fh_run: the widest row (columns) the device-side loop is offered for (fh_run_supported); 0 = the measured
                                 default 6144 (beyond it one launch per iteration issued by fh_iterate is as fast), at most 7168 = the widest
                                 row it has a kernel for                                                                             */
+  FH_TUNE_SEQ_POLL = 18,     /* 1 (default): a single-device step waits for its scalar block by the sequence number the launch writes behind
+                                it into host-mapped memory (~5 us sooner than the launch's completion signal); 0: hipStreamSynchronize (A/B)  */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
                                 reports).  The co-residency probe then asks for that many.  Lets several one-pass grids run side by side
                                 on one device: two solves at once, partitioned devices, ranks of a row-sharded run that share a GPU

@@ -11,8 +11,12 @@ sizes = [(512, 1024), (2048, 2048), (4096, 4096), (5000, 5000), (5632, 5632), (6
 if len(sys.argv) > 2:
     sizes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
 iters = 1024
+tuning = {hip.TUNE_RUN_MAX_N: 7168}
+if os.environ.get("FH_SEQ_POLL") == "0":          # A/B: wait for every launch with hipStreamSynchronize (rounds 1-5) instead of its sequence number
+    tuning[hip.TUNE_SEQ_POLL] = 0
+    print("# FH_TUNE_SEQ_POLL = 0: hipStreamSynchronize after every launch")
 for m, n in sizes:
-    A = fa.DenseMatrixMap.synthetic(m, n, seed=0, scale=synthetic.lasso_scale(m, n), tuning={hip.TUNE_RUN_MAX_N: 7168})
+    A = fa.DenseMatrixMap.synthetic(m, n, seed=0, scale=synthetic.lasso_scale(m, n), tuning=tuning)
     try:
         x_true = synthetic.sparse_signal(n, seed=1)
         b = synthetic.lasso_observation(A, x_true, seed_noise=2, sigma=0.01)
