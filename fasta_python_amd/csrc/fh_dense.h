@@ -177,8 +177,8 @@ __global__ __launch_bounds__(FH_WG) void k_fwd_dense(const FwdP p) {
     block_reduce<8>(v, s_scr, S_GMAX);
     if (tid == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) p.out[k] = v[k];
-      p.out[S_ALPHA] = level;
+      for (int k = 0; k < 8; ++k) scal_store(p.out + k, v[k]);
+      scal_store(p.out + S_ALPHA, level);
       publish_seq(p.out, p.px.seq);
       __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   for (uint32_t i = tid; i < p.nslab; i += FH_WG) w[5] += load_partial(p.red_f + i);
   block_reduce<6>(w, s_scr, 4);
   if (tid == 0) {
-    p.out[S_DXDG] = w[0]; p.out[S_DG2] = w[1]; p.out[S_XH2_ADJ] = w[2];
-    p.out[S_GSUM_ADJ] = w[3]; p.out[S_GMAX_ADJ] = w[4]; p.out[S_FSQ_ADJ] = w[5];
+    scal_store(p.out + S_DXDG, w[0]); scal_store(p.out + S_DG2, w[1]); scal_store(p.out + S_XH2_ADJ, w[2]);
+    scal_store(p.out + S_GSUM_ADJ, w[3]); scal_store(p.out + S_GMAX_ADJ, w[4]); scal_store(p.out + S_FSQ_ADJ, w[5]);
     publish_seq(p.out, p.seq);
     __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

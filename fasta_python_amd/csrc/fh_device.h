@@ -337,15 +337,14 @@ __device__ __forceinline__ bool arrive_last2(unsigned* base, volatile unsigned* 
 // hipStreamSynchronize -- i.e. from the completion signal of the whole launch, 14.8 us after its last instruction for an empty kernel; a
 // word the launch itself writes behind the block and the host spins on arrives after 10.0 (scripts/probes/bench_mem/launchgap.hip,
 // profiles/r06_launchgap.txt): 4-5 us off EVERY iteration of every operator.  The finalising thread calls this after its last store to the
-// block: its stores to host memory are acknowledged (vmcnt), then the sequence number follows as one system-scope store.  No cache
-// write-back is involved: the block is uncached host memory, and what the launch wrote to device memory is read only by later launches on
-// the same stream (or by copies ordered behind the launch's completion, as before).
+// block.  Visibility: every entry of the block is stored with a SYSTEM-scope store (write-through past L2: scal_store below) and the
+// sequence number follows as a system-scope RELEASE store (hipcc: buffer_wbl2 sc0 sc1, s_waitcnt vmcnt(0), then the store) -- the first
+// form of this, plain stores + vmcnt(0) + a relaxed store, let the host see the number BEFORE the block's entries (a stale FH_S_ALPHA in
+// tests/test_gpu_faults.py): plain stores to the mapped block may sit in L2 until the launch's end-of-kernel release.
 #define FH_SEQ_SLOT 28                       // in doubles from the start of the scalar block (FH_NSCALARS + 16 doubles are allocated)
+__device__ __forceinline__ void scal_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void publish_seq(double* out, unsigned seq) {
-  if (seq) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(reinterpret_cast<unsigned*>(out + FH_SEQ_SLOT), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (seq) __hip_atomic_store(reinterpret_cast<unsigned*>(out + FH_SEQ_SLOT), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // K doubles per workgroup, all held by thread 0 (the usual case after block_reduce)

@@ -638,14 +638,16 @@ __global__ __launch_bounds__(FH_WG, (fused_wpc<PPT, TEAM, XLDS, F32>())) void k_
     double bq[5] = {w[8], w[9], w[10], w[11], w[12]};
     block_reduce<5>(bq, s_scr, 4);
     if (tid == 0) {
-      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
-      p.out[S_GSUM] = a[5]; p.out[S_GMAX] = a[6]; p.out[S_RDOT] = rdot;   // every team computed the same restart dot
-      p.out[S_DXDG] = bq[0]; p.out[S_DG2] = bq[1]; p.out[S_XH2_ADJ] = bq[2]; p.out[S_GSUM_ADJ] = bq[3];
-      p.out[S_GMAX_ADJ] = bq[4]; p.out[S_FSQ_ADJ] = p.accel ? a[7] : a[0];
-      p.out[S_ALPHA] = level;
+      // (system-scope stores: the block may be host-mapped memory that the host reads as soon as the sequence number below arrives)
+      scal_store(p.out + S_FSQ, a[0]); scal_store(p.out + S_DXG0, a[1]); scal_store(p.out + S_DX2, a[2]); scal_store(p.out + S_XH2, a[3]);
+      scal_store(p.out + S_G02, a[4]); scal_store(p.out + S_GSUM, a[5]); scal_store(p.out + S_GMAX, a[6]);
+      scal_store(p.out + S_RDOT, rdot);   // every team computed the same restart dot
+      scal_store(p.out + S_DXDG, bq[0]); scal_store(p.out + S_DG2, bq[1]); scal_store(p.out + S_XH2_ADJ, bq[2]); scal_store(p.out + S_GSUM_ADJ, bq[3]);
+      scal_store(p.out + S_GMAX_ADJ, bq[4]); scal_store(p.out + S_FSQ_ADJ, p.accel ? a[7] : a[0]);
+      scal_store(p.out + S_ALPHA, level);
       if (p.coef_out) *p.coef_out = coef;
       const double timed_out = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;   // spin timeout?
-      p.out[15] = timed_out;
+      scal_store(p.out + 15, timed_out);
       if (p.pack) { p.pack[0] = a[0]; p.pack[1] = timed_out; p.pack[2] = p.accel ? a[7] : a[0]; }
       publish_seq(p.out, p.px.seq);
       // leave the counters zero for the next launch (every workgroup is past the grid barrier and has taken its final ticket)

@@ -676,9 +676,15 @@ static int launch_tv_onepass(fh_ctx* c, double tau, int accel, double coef, int 
     // workgroups run side by side and finish together -- 2240 workgroups of 128 rows on 1280 slots ran 1.75 rounds, the last one
     // three-quarters empty (8192^2: 128 rows 0.607 ms, 228-235 rows 0.588; profiles/r02_tune_tv.txt, r03_tune_tv.txt).  At least
     // 32 rows per chunk (rows + 4 are read and computed), at most the image.
+    // SMALL images (round 6; the reference's own example is 512 x 512, tv_denoising.py:113-125): a chunk's rows are walked two (four) at a
+    // time, each trip a dependent ~1-us round trip to L2 -- with 32-row chunks a 512^2 sweep is 48 workgroups x 18 trips = 23 us for 10 MB.
+    // 8-row chunks (192 workgroups x 6 trips) take 16.5 us, 4 and 16 rows 18.5; at 1024^2 the plain sweep gains the same way (36.0 -> 27.9 us),
+    // the FISTA sweep (two streams, 4-row trips) does not (31.0 -> 35.2); from 2048^2 on 32 rows are best again (profiles/r06_tv_rows_small.txt).
+    const uint64_t pixels = (uint64_t)p.H * p.W;
+    const uint32_t min_rows = pixels <= (1u << 18) ? 8u : ((pixels <= (1u << 20) && !accel) ? 8u : 32u);
     const uint32_t slots = (uint32_t)std::max(1, c->ncu) * 5u;
     const uint32_t chunks = std::max(1u, slots / p.strip_groups);
-    p.rows_wg = std::min(p.H, std::max(32u, (p.H + chunks - 1) / chunks));
+    p.rows_wg = std::min(p.H, std::max(min_rows, (p.H + chunks - 1) / chunks));
   }
   // rows per trip / rotating trip buffers: 2 rows, load-then-consume for the plain sweep; 4 rows x 3 rotating buffers with FISTA
   // (two streams to read): profiles/r03_tune_tv.txt.  Every combination produces the same bits (scripts/probes/tune_tvz.py).

@@ -1212,16 +1212,17 @@ __global__ __launch_bounds__(FH_WG) void k_tv_onepass(const TvZP p) {
       const double gmax1 = fmax(fmax(s_scr[1], s_scr[3]), fmax(s_scr[5], s_scr[7]));
       const double rdot = ACCEL ? a[5] : 0.0;
       const bool plain = !ACCEL || (p.restart && rdot > 1E-30) || p.coef == 0.0;      // :231 -- the branch the reference takes
-      p.out[S_FSQ] = a[0]; p.out[S_DXG0] = a[1]; p.out[S_DX2] = a[2]; p.out[S_XH2] = a[3]; p.out[S_G02] = a[4];
-      p.out[S_GSUM] = bq[0]; p.out[S_GMAX] = gmax0; p.out[S_RDOT] = rdot;
-      p.out[S_DXDG] = plain ? a[6] : bq[1];
-      p.out[S_DG2] = plain ? a[7] : bq[2];
-      p.out[S_XH2_ADJ] = plain ? a[3] : bq[3];
-      p.out[S_GSUM_ADJ] = plain ? bq[0] : bq[4];
-      p.out[S_GMAX_ADJ] = plain ? gmax0 : gmax1;
-      p.out[S_FSQ_ADJ] = plain ? a[0] : bq[5];
-      p.out[S_ALPHA] = 0.0;
-      p.out[15] = 0.0;
+      // (system-scope stores: the block is host-mapped memory that the host reads as soon as the sequence number below arrives)
+      scal_store(p.out + S_FSQ, a[0]); scal_store(p.out + S_DXG0, a[1]); scal_store(p.out + S_DX2, a[2]); scal_store(p.out + S_XH2, a[3]);
+      scal_store(p.out + S_G02, a[4]); scal_store(p.out + S_GSUM, bq[0]); scal_store(p.out + S_GMAX, gmax0); scal_store(p.out + S_RDOT, rdot);
+      scal_store(p.out + S_DXDG, plain ? a[6] : bq[1]);
+      scal_store(p.out + S_DG2, plain ? a[7] : bq[2]);
+      scal_store(p.out + S_XH2_ADJ, plain ? a[3] : bq[3]);
+      scal_store(p.out + S_GSUM_ADJ, plain ? bq[0] : bq[4]);
+      scal_store(p.out + S_GMAX_ADJ, plain ? gmax0 : gmax1);
+      scal_store(p.out + S_FSQ_ADJ, plain ? a[0] : bq[5]);
+      scal_store(p.out + S_ALPHA, 0.0);
+      scal_store(p.out + 15, 0.0);
       publish_seq(p.out, p.seq);
     }
   }

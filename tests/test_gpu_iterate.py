@@ -228,3 +228,40 @@ def test_fh_iterate_reports_completed_iterations_when_a_later_one_fails():
         assert not np.array_equal(c.get_vector(hip.VEC_X0, n), x_before)
     finally:
         op.close()
+
+
+@pytest.mark.parametrize("kind", ["dense_one_pass", "dense_two_launches", "dense_pair", "tv", "tv_accelerated", "l1ball"])
+def test_scalars_by_sequence_number_are_the_scalars_after_a_stream_synchronisation(kind):
+    """Round 6: a single-device step no longer waits for the launch's completion signal but for a sequence number the launch's finaliser
+    writes behind the host-mapped scalar block (csrc/fh_device.h:publish_seq, FH_TUNE_SEQ_POLL).  Whatever the host reads after that number
+    must be what it reads after hipStreamSynchronize: a few hundred iterations of every kind of launch, both ways, EQUAL histories --
+    a stale entry of the block (the first form of the hand-off had one) changes a decision or a residual somewhere."""
+    rng = np.random.RandomState(23)
+    if kind.startswith("tv"):
+        op, loss, reg, x0 = _problem("tv", rng)
+        extra = dict(adaptive=False, accelerate=True) if kind == "tv_accelerated" else {}
+    else:
+        m, n = (64, 20000) if kind == "l1ball" else ((700, 1100) if kind != "dense_pair" else (300, 900))
+        A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+        b = rng.randn(m)
+        op, loss, x0 = fa.DenseMatrixMap(A), fa.LeastSquares(b), np.zeros(n)
+        reg = fa.L1Ball(4.0) if kind == "l1ball" else fa.Shrink(0.03)
+        extra = dict(fused=False) if kind == "dense_two_launches" else {}
+    runs = []
+    try:
+        if kind == "dense_pair":
+            op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_PROBE_SAYS_NO)          # no one-pass kernel: K-fwd + K-adj under one wait
+        for poll in (1, 0, 1):
+            op.ctx.set_tuning(hip.TUNE_SEQ_POLL, poll)
+            np.random.seed(8)
+            solver = fa.FBSolver(op, loss, reg, x0, verbose=False, max_iters=300, tolerance=0.0, evaluate_objective=True, **extra)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                runs.append((solver.setup().run(), solver.mode))
+    finally:
+        op.close()
+    assert runs[0][1] == {"dense_one_pass": "speculative", "dense_two_launches": None, "dense_pair": "pair"}.get(kind, "always")      # (l1ball: n >= 16384)
+    assert runs[0][0].iteration_count == 300
+    _assert_identical(runs[1][0], runs[0][0], kind)
+    _assert_identical(runs[2][0], runs[0][0], kind)
+
