@@ -224,8 +224,23 @@ extern "C" int fh_destroy(fh_ctx* c) {
   return 0;
 }
 
-// process-wide: wait (or not) with a large matrix allocation until this process's earlier large frees have been cleared by the driver
+// process-wide switches of the two remedies for "a large allocation made while the driver is still clearing a large free is slow" (fh_host_ctx.h)
 extern "C" int fh_alloc_settle(int enable) { g_settle_on.store(enable ? 1 : 0); return 0; }
+extern "C" int fh_alloc_cache(int enable) {
+  g_cache_on.store(enable ? 1 : 0);
+  if (!enable) release_cached_blocks(-1);
+  return 0;
+}
+extern "C" int fh_release_cached(int device) {
+  if (device < -1 || device >= FH_MAX_DEVICES) return fail(FH_E_ARG, "fh_release_cached: device must be -1 (all) or a device id");
+  release_cached_blocks(device);
+  return 0;
+}
+extern "C" int fh_alloc_cache_hits(uint64_t* hits) {
+  if (!hits) return fail(FH_E_ARG, "null argument");
+  *hits = g_cache_hits.load();
+  return 0;
+}
 extern "C" int fh_alloc_settle_waited(double* seconds) {
   if (!seconds) return fail(FH_E_ARG, "null argument");
   *seconds = (double)g_settle_waited_ns.load() * 1e-9;
@@ -337,8 +352,7 @@ static int setup_dense(fh_ctx* c, uint64_t m, uint64_t n) {
   c->ld = round_up(n, c->f32 ? 32 : 16) + (uint64_t)c->ld_pad;      // rows stay 128-byte aligned in either storage
   c->nv = c->ld; c->mv = c->mp;
   const size_t a_bytes = (size_t)c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double));
-  settle_before_large_alloc(a_bytes);             // (a large free of this process may still be being cleared: fh_host_ctx.h)
-  HIP_TRY(hipMalloc((void**)&c->A, a_bytes));
+  HIP_TRY(acquire_matrix_block(c->device, a_bytes, &c->A, &c->a_block_bytes));      // the block this device kept from an earlier matrix, or a fresh one behind the settle wait (fh_host_ctx.h)
   FH_TRY(alloc_vectors(c));
   c->op = OP_DENSE;
   return 0;

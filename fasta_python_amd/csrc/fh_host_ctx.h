@@ -110,6 +110,7 @@ struct fh_ctx {
   uint64_t nv = 0, mv = 0;   // allocated n-side / m-side vector lengths (doubles)
   uint64_t H = 0, W = 0;
   double* A = nullptr;
+  size_t a_block_bytes = 0;  // size of the block A lives in (>= the matrix: a kept block may be up to twice as large, see acquire_matrix_block)
   // n-side
   // iterate pool: X[xi] = x0, X[ti] = where the next x1 lands, X[bi] = best-quality iterate (may alias X[xi]):
   // the best iterate is tracked by index, never copied (a 1 GiB copy per improving iteration at 8192^2 TV)
@@ -252,35 +253,91 @@ static int use_device(fh_ctx* c) {
 }
 
 // ---- large frees and the allocations behind them -------------------------------------------------------------------------------------
-// The driver clears freed device memory in the background, ~30 ms per GiB on MI355X: meanwhile a read-only stream over OTHER memory runs
-// 3 % slow, and -- what matters here -- a large allocation made while the clearing is still going on can come out 6-8 % slow for its whole
-// lifetime (profiles/r05_free_aftermath.txt: the "wide-row / config-5 outlier" of the round-3..5 bench lines).  The library therefore
-// remembers, process-wide, when its own large frees will have been cleared and lets the next large matrix allocation wait for that moment
-// (fh_alloc_settle(0) switches the wait off; fh_alloc_settle_waited reports what it has cost so far).
-static std::atomic<long long> g_clear_until_ns{0};       // steady clock
+// The driver clears freed device memory in the background, ~30 ms per GiB on MI355X.  Meanwhile a read-only stream over OTHER memory runs
+// 0.7-3 % slow -- and a large allocation made while the clearing is still going on comes out 13-14 % slow FOR ITS WHOLE LIFETIME: 6 of 6
+// interleaved cycles of { 128 GiB freed, 32 GiB allocated at once, 300 steps } at 5.49-5.54 ms per step against 4.85-4.89 with the remedies
+// below (profiles/r06_alloc_settle.txt; round 5 had seen it once).  Two remedies, both PER DEVICE:
+//   1. re-use (deterministic: no clearing, no new mapping, no sleep): the matrix block (>= 1 GiB) a context gives up is not returned to the
+//      driver but kept -- one block per device -- and handed to the next matrix on that device that fits it and fills at least half of it;
+//      fh_release_cached() / fh_alloc_cache(0) return it to the driver.
+//   2. settle: a matrix that cannot be served that way is allocated only after the device's earlier large frees have presumably been cleared
+//      (35 ms per GiB behind the free); fh_alloc_settle(0) switches the wait off, fh_alloc_settle_waited reports what it has cost so far.
+#include <mutex>
+#define FH_MAX_DEVICES 64
+static std::atomic<long long> g_clear_until_ns[FH_MAX_DEVICES];       // steady clock, per device
 static std::atomic<long long> g_settle_waited_ns{0};
 static std::atomic<int> g_settle_on{1};
+static std::atomic<int> g_cache_on{1};
+static std::atomic<unsigned long long> g_cache_hits{0};
+struct CachedBlock { double* p = nullptr; size_t bytes = 0; };
+static std::mutex g_cache_mu;
+static CachedBlock g_cache[FH_MAX_DEVICES];
 static const size_t kSettleMinBytes = (size_t)1 << 30;
 static const double kClearNsPerByte = 35.0e6 / (double)((size_t)1 << 30);     // 35 ms per GiB (measured: 2.9 s for 96 GiB)
 static long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static void note_large_free(size_t bytes) {
+static inline int dev_slot(int device) { return device >= 0 && device < FH_MAX_DEVICES ? device : 0; }
+static void note_large_free(int device, size_t bytes) {
   if (bytes < kSettleMinBytes) return;
+  std::atomic<long long>& until = g_clear_until_ns[dev_slot(device)];
   const long long now = steady_ns(), add = (long long)(kClearNsPerByte * (double)bytes);
-  long long cur = g_clear_until_ns.load();
-  while (!g_clear_until_ns.compare_exchange_weak(cur, std::max(cur, now) + add)) { }
+  long long cur = until.load();
+  while (!until.compare_exchange_weak(cur, std::max(cur, now) + add)) { }
 }
-static void settle_before_large_alloc(size_t bytes) {
+static void settle_before_large_alloc(int device, size_t bytes) {
   if (!g_settle_on.load() || bytes < kSettleMinBytes) return;
-  const long long wait = g_clear_until_ns.load() - steady_ns();
+  const long long wait = g_clear_until_ns[dev_slot(device)].load() - steady_ns();
   if (wait <= 0) return;
   std::this_thread::sleep_for(std::chrono::nanoseconds(wait));
   g_settle_waited_ns.fetch_add(wait);
+}
+// a context gives up its matrix block: kept for the next matrix on this device (the block it displaces goes back to the driver), or freed
+static void release_matrix_block(int device, double* p, size_t bytes) {
+  if (!p) return;
+  if (bytes >= kSettleMinBytes && g_cache_on.load()) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CachedBlock& cb = g_cache[dev_slot(device)];
+    if (cb.p) { (void)hipFree(cb.p); note_large_free(device, cb.bytes); }
+    cb.p = p; cb.bytes = bytes;
+    return;
+  }
+  (void)hipFree(p);
+  note_large_free(device, bytes);
+}
+// a block for a matrix of `bytes` on `device` (the current device): the kept one if it fits and is at most twice as large, else a fresh one
+// behind the settle wait.  *got = the size of the block handed out.
+static hipError_t acquire_matrix_block(int device, size_t bytes, double** out, size_t* got) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CachedBlock& cb = g_cache[dev_slot(device)];
+    if (cb.p && cb.bytes >= bytes && cb.bytes / 2 <= bytes) {
+      *out = cb.p; *got = cb.bytes;
+      cb = CachedBlock();
+      g_cache_hits.fetch_add(1);
+      return hipSuccess;
+    }
+    if (cb.p && bytes >= kSettleMinBytes) {            // it cannot serve this matrix and would only stand in its way: back to the driver
+      (void)hipFree(cb.p); note_large_free(device, cb.bytes);
+      cb = CachedBlock();
+    }
+  }
+  settle_before_large_alloc(device, bytes);
+  *got = bytes;
+  return hipMalloc((void**)out, bytes);
+}
+static void release_cached_blocks(int device /* -1 = all */) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (int d = 0; d < FH_MAX_DEVICES; ++d) {
+    if ((device >= 0 && d != device) || !g_cache[d].p) continue;
+    (void)hipSetDevice(d);
+    (void)hipFree(g_cache[d].p); note_large_free(d, g_cache[d].bytes);
+    g_cache[d] = CachedBlock();
+  }
 }
 
 static void free_operator(fh_ctx* c) {
   for (fh_ctx* s : c->shards) { (void)hipSetDevice(s->device); free_operator(s); }
   auto fr = [](double*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  if (c->A && c->op == OP_DENSE) note_large_free((size_t)c->mp * c->ld * (c->f32 ? sizeof(float) : sizeof(double)));
+  if (c->A && c->op == OP_DENSE) { release_matrix_block(c->device, c->A, c->a_block_bytes); c->A = nullptr; c->a_block_bytes = 0; }
   fr(c->A);
   for (int i = 0; i < 2; ++i) { fr(c->P[i]); fr(c->G[i]); fr(c->Z[i]); }
   for (int i = 0; i < 3; ++i) fr(c->X[i]);

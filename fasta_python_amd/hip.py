@@ -114,6 +114,9 @@ SIGNATURES = {
     "fh_comm_version": (_i32, [C.POINTER(_i32)]),
     "fh_alloc_settle": (_i32, [_i32]),
     "fh_alloc_settle_waited": (_i32, [C.POINTER(_dbl)]),
+    "fh_alloc_cache": (_i32, [_i32]),
+    "fh_release_cached": (_i32, [_i32]),
+    "fh_alloc_cache_hits": (_i32, [C.POINTER(_u64)]),
     "fh_comm_selftest": (_i32, [_ctx, _u64, _pd, C.POINTER(_i32)]),
     "fh_cu_count": (_i32, [_ctx, C.POINTER(_i32), C.POINTER(_i32)]),
     "fh_timing_enable": (_i32, [_ctx, _i32]),
@@ -203,10 +206,30 @@ def comm_version():
 
 
 def alloc_settle(enable=True):
-    """Process-wide: wait with a large (>= 1 GiB) matrix allocation until this process's earlier large frees have been cleared by the driver
-    (default on; see include/fasta_hip.h and profiles/r05_free_aftermath.txt)."""
+    """Process-wide: wait with a large (>= 1 GiB) matrix allocation that no kept block serves until the device's earlier large frees have
+    been cleared by the driver (default on; see include/fasta_hip.h and profiles/r06_alloc_settle.txt)."""
     lib = load_library()
     _check(lib, lib.fh_alloc_settle(1 if enable else 0))
+
+
+def alloc_cache(enable=True):
+    """Process-wide: keep the matrix block (>= 1 GiB) a context gives up -- one per device -- for the next matrix on that device that fits it
+    (default on: no clearing, no new mapping, no waiting; include/fasta_hip.h).  False also returns the kept blocks to the driver."""
+    lib = load_library()
+    _check(lib, lib.fh_alloc_cache(1 if enable else 0))
+
+
+def release_cached(device=-1):
+    """Return the kept matrix block of `device` (-1: of every device) to the driver."""
+    lib = load_library()
+    _check(lib, lib.fh_release_cached(int(device)))
+
+
+def alloc_cache_hits():
+    lib = load_library()
+    n = _u64(0)
+    _check(lib, lib.fh_alloc_cache_hits(C.byref(n)))
+    return int(n.value)
 
 
 def alloc_settle_waited():

@@ -325,13 +325,19 @@ int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
 /* ranks of the attached communicator as RCCL reports them (ncclCommCount); 1 without a communicator */
 int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
-/* Large frees and the allocations behind them (process-wide).  The driver clears freed device memory in the background (~30 ms per GiB on
- * MI355X); a large allocation made meanwhile can come out 6-8 % slow for its whole lifetime (profiles/r05_free_aftermath.txt).  By default
- * fh_set_matrix / fh_generate_matrix wait, before allocating a matrix of >= 1 GiB, until the matrices (>= 1 GiB) this process has freed through
- * the library have presumably been cleared (35 ms per GiB behind the free).  fh_alloc_settle(0) switches that wait off, fh_alloc_settle(1) on;
- * fh_alloc_settle_waited returns the seconds spent waiting so far.                                                                          */
+/* Large frees and the allocations behind them.  The driver clears freed device memory in the background (~30 ms per GiB on MI355X); a large
+ * allocation made meanwhile comes out 13-14 % slow for its whole lifetime (profiles/r06_alloc_settle.txt: 6 of 6 cycles).  Two remedies, per device:
+ *   - the matrix block (>= 1 GiB) a context gives up (fh_destroy, a new fh_set_matrix / fh_generate_matrix / fh_set_stencil) is KEPT, one block
+ *     per device, and handed to the next matrix on that device that fits it and fills at least half of it: no clearing, no new mapping, no
+ *     waiting.  The memory stays allocated until then: fh_release_cached(device | -1 = all) returns it to the driver, fh_alloc_cache(0)
+ *     switches the keeping off (and releases), fh_alloc_cache_hits counts the re-uses;
+ *   - a matrix of >= 1 GiB that no kept block serves is allocated only after the device's earlier large frees have presumably been cleared
+ *     (35 ms per GiB behind the free): fh_alloc_settle(0) switches that wait off, fh_alloc_settle_waited returns the seconds spent in it.   */
 int fh_alloc_settle(int enable);
 int fh_alloc_settle_waited(double* seconds);
+int fh_alloc_cache(int enable);
+int fh_release_cached(int device);
+int fh_alloc_cache_hits(uint64_t* hits);
 
 /* RCCL's version code as ncclGetVersion reports it; -1 when no library is loaded yet or it does not export the symbol           */
 int fh_comm_version(int* version);

@@ -413,31 +413,43 @@ def test_fwd_adj_under_one_sync_equals_fwd_then_adj(m, n):
         op.close()
 
 
-def test_a_large_allocation_waits_for_the_clearing_of_a_large_free():
-    """fh_alloc_settle (process-wide, default on): a matrix of >= 1 GiB allocated right behind the free of one waits ~35 ms per GiB freed -- the driver
-    clears freed memory in the background and an allocation made meanwhile can come out 6-8 % slow for its lifetime (profiles/r05_free_aftermath.txt);
-    switched off, it does not wait; small matrices never do."""
+def test_a_large_allocation_reuses_the_kept_block_or_waits_for_the_clearing_of_a_large_free():
+    """A matrix of >= 1 GiB allocated while the driver still clears a large free comes out 13-14 % slow for its lifetime (profiles/r06_alloc_settle.txt).
+    Default: the block a context gives up is kept, per device, and handed to the next matrix that fits it and fills at least half of it (no wait);
+    a matrix it cannot serve waits ~35 ms per GiB freed (fh_alloc_settle), unless that is switched off; small matrices never do either."""
     import time
+    hip.release_cached()
     time.sleep(0.3)                                       # (frees of earlier tests)
-    gib2 = (16384, 16384)                                 # 2 GiB
-    def cycle():
-        a = fa.DenseMatrixMap.synthetic(*gib2, 0, 1e-3); a.close()
-        w0, t0 = hip.alloc_settle_waited(), time.perf_counter()
-        b = fa.DenseMatrixMap.synthetic(*gib2, 0, 1e-3)
-        waited, wall = hip.alloc_settle_waited() - w0, time.perf_counter() - t0
+    gib2, gib1 = (16384, 16384), (8192, 16384)            # 2 GiB, 1 GiB
+    def cycle(second, cache):
+        hip.alloc_cache(cache)
+        a = fa.DenseMatrixMap.synthetic(*gib2, 0, 1e-3)
+        ref = a.host_rows(0, 2).copy()
+        a.close()
+        w0, h0, t0 = hip.alloc_settle_waited(), hip.alloc_cache_hits(), time.perf_counter()
+        b = fa.DenseMatrixMap.synthetic(*second, 0, 1e-3)
+        waited, hits, wall = hip.alloc_settle_waited() - w0, hip.alloc_cache_hits() - h0, time.perf_counter() - t0
+        rows = b.host_rows(0, 2)
         b.close()
-        return waited, wall
-    waited, wall = cycle()
-    assert 0.02 < waited < 0.2 and wall >= waited, (waited, wall)          # 2 GiB freed -> ~70 ms, minus what the free itself took
-    time.sleep(0.3)
-    hip.alloc_settle(False)
+        hip.release_cached()
+        time.sleep(0.3)
+        return waited, hits, wall, ref, rows
     try:
-        waited, _ = cycle()
-        assert waited == 0.0
+        waited, hits, wall, ref, rows = cycle(gib2, True)              # same size: the kept block, no wait, the right matrix in it
+        assert hits == 1 and waited == 0.0 and np.array_equal(ref, rows)
+        waited, hits, wall, ref, rows = cycle(gib1, True)              # half the size: still the kept block
+        assert hits == 1 and waited == 0.0 and np.array_equal(rows[:, :5], fa.DenseMatrixMap.synthetic(8, 16384, 0, 1e-3).host_rows(0, 2)[:, :5])
+        waited, hits, wall, _, _ = cycle((4500, 16384), True)          # 0.55 GiB... below the 1 GiB threshold: neither kept-block logic nor a wait applies
+        assert hits == 0 and waited == 0.0
+        waited, hits, wall, _, _ = cycle(gib2, False)                  # keeping off: the block is freed, the next allocation waits for its clearing
+        assert hits == 0 and 0.02 < waited < 0.2 and wall >= waited, (waited, wall)
+        hip.alloc_settle(False)
+        waited, hits, _, _, _ = cycle(gib2, False)
+        assert hits == 0 and waited == 0.0
     finally:
         hip.alloc_settle(True)
-    time.sleep(0.3)
+        hip.alloc_cache(True)
     a = fa.DenseMatrixMap.synthetic(4096, 4096, 0, 1e-3); a.close()          # 128 MiB: below the threshold
-    w0 = hip.alloc_settle_waited()
+    w0, h0 = hip.alloc_settle_waited(), hip.alloc_cache_hits()
     b = fa.DenseMatrixMap.synthetic(4096, 4096, 0, 1e-3); b.close()
-    assert hip.alloc_settle_waited() == w0
+    assert hip.alloc_settle_waited() == w0 and hip.alloc_cache_hits() == h0
