@@ -70,9 +70,22 @@ for c in range(cycles):
             table[mode].append(ms)
         A.close()
         time.sleep(6.0)          # (every case starts from a device whose earlier frees have been cleared)
-hip.alloc_settle(True)
+# remedy 1 (kept-block re-use): a 32 GiB matrix given up and a 32 GiB matrix allocated AT ONCE -- the kept block (no wait) against a fresh
+# allocation with neither remedy
+for c in range(3):
+    for mode in ("reuse", "neither"):
+        hip.alloc_cache(mode == "reuse"); hip.alloc_settle(False)
+        A = matrix(); A.ctx.sync(); A.close()
+        h0 = hip.alloc_cache_hits()
+        A = matrix()
+        ms = steps_ms(A, b)
+        print(f"[{c}] 32 GiB right behind the release of a 32 GiB matrix, {mode:7s} (kept-block hits {hip.alloc_cache_hits() - h0}): {fmt(ms)}", flush=True)
+        table.setdefault(mode, []).append(ms)
+        A.close(); hip.release_cached()
+        time.sleep(3.0)
+hip.alloc_settle(True); hip.alloc_cache(True)
 print("\nsummary, ms per step (mean of the 3 x 100-step samples of each cycle):")
-for mode in ("off", "on", "control"):
+for mode in ("off", "on", "control", "reuse", "neither"):
     means = [float(np.mean(v[:3])) for v in table[mode]]
     print(f"  {mode:8s}: " + " ".join(f"{m:.3f}" for m in means) + f"   | worst {max(means):.3f}, best {min(means):.3f}")
 slow = sum(1 for v in table["off"] if np.mean(v) > 1.03 * min(np.mean(w) for w in table["on"] + table["off"]))
