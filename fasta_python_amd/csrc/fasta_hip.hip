@@ -1009,9 +1009,15 @@ static const RunEntry* run_entry(fh_ctx* c) {
   // a workgroup owns whole rows: 16-byte pieces per lane = the first table entry that covers the row (lanes past the row's end re-read its last piece)
   const uint64_t pieces = round_up(c->n, 16) / 2;
   if (c->ld % 2 || pieces == 0 || pieces > (uint64_t)FH_WG * 14) return nullptr;
-  // ... up to the width where the persistent launch still beats one launch per iteration issued by fh_iterate (FH_TUNE_RUN_MAX_N overrides:
-  // profiles/r06_device_loop.txt has both drivers at every width up to 7168)
-  if (c->n > (uint64_t)(c->run_max_n > 0 ? c->run_max_n : kRunDefaultMaxN)) return nullptr;
+  // ... and it is OFFERED only where it beats one launch per iteration issued by fh_iterate (profiles/r06_device_loop.txt: a grid of 36 shapes, ratio
+  // device / library loop): whole rows in LDS (n <= 4096) up to 32 Mi elements -- beyond, the launches are long enough to hide their fixed cost and the
+  // team kernel streams faster (4096 x 16384: 0.96, 2048 x 32768: 0.95); the wide shapes (n <= 6144) from 4096 rows on -- below, the redundant n-side
+  // work of every workgroup costs more than a launch (1024 x 6144: 0.94) -- up to 40 Mi elements (8192 x 6144: 0.97; 6144^2: 1.08, 4096 x 6144: 1.19).
+  // FH_TUNE_RUN_MAX_N = N replaces the window by "n <= N, any m" (tests, probes).
+  if (c->run_max_n > 0) { if (c->n > (uint64_t)c->run_max_n) return nullptr; }
+  else if (c->n <= 4096) { if (c->m * c->n > ((uint64_t)1 << 25)) return nullptr; }
+  else if (c->n <= (uint64_t)kRunDefaultMaxN) { if (c->m < 4096 || c->m * c->n > ((uint64_t)40 << 20)) return nullptr; }
+  else return nullptr;
   const int need = (int)((pieces + FH_WG - 1) / FH_WG);
   for (const RunEntry& e : kRunTable) if (e.ppt >= need) return &e;
   return nullptr;

@@ -108,9 +108,10 @@ enum fh_tuning_key {
                                 cache lines share an L2 (0 = auto = 1 = on, 2 = off: plain blockIdx order)                    */
   /* keys 13-15 (occupancy limiter, LDS-DMA trip ring, persistent chunk walk of the stencil sweep: measured flat twice,
      profiles/r04_tune_tv.txt) are only present in -DFH_EXPERIMENTAL builds (csrc/fh_experimental.h); FH_E_ARG otherwise        */
-  FH_TUNE_RUN_MAX_N = 17,    /* fh_run: the widest row (columns) the device-side loop is offered for (fh_run_supported); 0 = the measured
-                                default 6144 (beyond it one launch per iteration issued by fh_iterate is as fast), at most 7168 = the widest
-                                row it has a kernel for                                                                             */
+  FH_TUNE_RUN_MAX_N = 17,    /* fh_run: the widest row (columns) the device-side loop is offered for (fh_run_supported), whatever the number of
+                                rows; 0 = the measured window (profiles/r06_device_loop.txt): n <= 4096 up to 32 Mi elements, n <= 6144 from 4096 rows
+                                on up to 40 Mi elements -- elsewhere one launch per iteration issued by fh_iterate is as fast or faster; at most
+                                7168 = the widest row it has a kernel for                                                          */
   FH_TUNE_SEQ_POLL = 18,     /* 1 (default): a single-device step waits for its scalar block by the sequence number the launch writes behind
                                 it into host-mapped memory (~5 us sooner than the launch's completion signal); 0: hipStreamSynchronize (A/B)  */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
@@ -261,7 +262,7 @@ int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* sca
  *   history max_steps records of FH_RUN_HIST doubles: residual, norm_residual, stepsize, f_hist[i+1], objective, backtracks of the
  *           iteration, alpha0, 1 if the iterate became the best one (+ 2 if the acceleration was restarted, :231-233)
  *   steps_done  iterations executed (fewer than max_steps when the stop rule fired: state->stopped = 1)
- * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator with n <= 6144 -- FH_TUNE_RUN_MAX_N -- on a
+ * fh_run_supported: 1 if this context's operator, loss and prox have a kernel for it (dense float64 operator inside the measured window of FH_TUNE_RUN_MAX_N -- n <= 6144, at most 32-40 Mi elements -- on a
  * single-device context, a scalar-separable prox without level search, every CU free for one resident workgroup).                 */
 #define FH_RUN_HIST 8
 #define FH_RUN_WINDOW_MAX 64

@@ -110,7 +110,7 @@ def test_a_grid_barrier_timeout_of_the_device_loop_keeps_the_solve(m, n, mode, a
     A, b = _run_problem(m, n)
     ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
     opts = dict(verbose=False, backend="hip", max_iters=90, tolerance=1e-7, evaluate_objective=True, device_iters=32, **RUN_MODES[mode])
-    op = fa.DenseMatrixMap(A)
+    op = fa.DenseMatrixMap(A, tuning={hip.TUNE_RUN_MAX_N: 7168})          # (the wide shape with few rows lies outside the window fh_run is offered in by default)
     try:
         np.random.seed(5)
         with warnings.catch_warnings():

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import fasta_python_amd as fa
+from fasta_python_amd import hip
 from oracle import fasta_np as fo
 from oracle import problems as pr
 
@@ -219,7 +220,13 @@ def test_random_shapes_modes_and_launch_lengths_with_the_loop_on_the_device(seed
     reg, P = {"shrink": (fa.Shrink(mu), pr.sparse_least_squares_from(A, b, mu)), "nonneg": (fa.NonNeg(), pr.nn_least_squares_from(A, b))}[kind]
     ls = fa.LeastSquares(b)
     np.random.seed(seed)
-    got = fa.fasta(A, A.T, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", device_iters=int(rng.randint(1, 40)), **opts)
+    # (FH_TUNE_RUN_MAX_N: by default the device loop is offered only where it beats the library's host-side loop -- not for a few hundred
+    #  wide rows; the kernel is exercised on every width it has)
+    op = fa.DenseMatrixMap(A, tuning={hip.TUNE_RUN_MAX_N: 7168})
+    try:
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, x0, verbose=False, backend="hip", device_iters=int(rng.randint(1, 40)), **opts)
+    finally:
+        op.close()
     assert got.device_steps == got.iteration_count, "the device loop did not take this solve"
     oracle_opts = dict(opts, stop_rule=getattr(fo, rule))
     np.random.seed(seed)

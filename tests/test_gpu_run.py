@@ -76,7 +76,7 @@ def test_device_loop_equals_the_per_iteration_path_and_the_oracle(m, n, mode):
     b = A @ xt + 0.01 * rng.randn(m)
     opts = dict(tolerance=1e-7, max_iters=120, evaluate_objective=True, **MODES[mode])
     # (rows wider than 6144 columns are offered to fh_run only on request -- FH_TUNE_RUN_MAX_N: there the per-iteration launches are as fast)
-    tuning = {hip.TUNE_RUN_MAX_N: 7168} if n > 6144 else None
+    tuning = {hip.TUNE_RUN_MAX_N: 7168} if n > 4096 else None          # (the wide shapes are offered from 4096 rows on by default: FH_TUNE_RUN_MAX_N lifts the window)
     host = _solve(A, b, fa.Shrink(0.02), np.zeros(n), fused=True, **opts)
     dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), tuning=tuning, device_iters=16, **opts)
     assert host.device_steps == 0 and dev.device_steps == dev.iteration_count
@@ -158,6 +158,10 @@ def test_options_that_need_the_host_between_iterations_keep_the_per_iteration_pa
     assert wide.device_steps == 0 and wide.library_steps == wide.iteration_count == 10
     beyond = _solve(rng.randn(50, 7000) / 100, rng.randn(50), fa.Shrink(0.02), np.zeros(7000), device_iters=8, max_iters=10)   # n > 6144: a kernel, but not offered by default
     assert beyond.device_steps == 0 and beyond.library_steps == 10
+    few_rows = _solve(rng.randn(64, 5000) / 100, rng.randn(64), fa.Shrink(0.02), np.zeros(5000), device_iters=8, max_iters=10)  # wide rows, few of them: not offered either
+    assert few_rows.device_steps == 0 and few_rows.library_steps == 10
+    inside = _solve(rng.randn(4096, 4100) / 100, rng.randn(4096), fa.Shrink(0.02), np.zeros(4100), device_iters=8, max_iters=10)   # ... and offered from 4096 rows on
+    assert inside.device_steps == 10
 
 
 def test_operators_without_a_device_loop_keep_the_per_iteration_path():
