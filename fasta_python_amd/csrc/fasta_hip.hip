@@ -53,6 +53,33 @@ static const FusedEntry kFusedTable[] = {
 #undef FUSED_INST_2
 #undef FUSED_INST_3
 
+// the chained form of the one-pass launch (k_fused_chain, csrc/fh_fused.h): group 0 of the same table -- float64, teams of 1 / 2 / 4 (fh_chain_part.hip)
+#ifndef FH_SINGLE_TU
+#define FH_CHAIN_DECLARE(P, PI, T, X, NB, F) extern template __global__ void k_fused_chain<P, 1, PI, T, X, NB, F>(const FusedP, const ChainP);
+#define FUSED_INST_0 FH_CHAIN_DECLARE
+#define FUSED_INST_1(...)
+#define FUSED_INST_2(...)
+#define FUSED_INST_3(...)
+#include "fh_fused_instances.inc"
+#undef FUSED_INST_0
+#undef FUSED_INST_1
+#undef FUSED_INST_2
+#undef FUSED_INST_3
+#endif
+struct ChainEntry { int ppt, pipe, team, xlds, nbo, f32; void (*kernel)(const FusedP, const ChainP); };
+#define FH_CHAIN_ROW(P, PI, T, X, NB, F) {P, PI, T, X, NB, F, k_fused_chain<P, 1, PI, T, X, NB, F>},
+#define FUSED_INST_0 FH_CHAIN_ROW
+#define FUSED_INST_1(...)
+#define FUSED_INST_2(...)
+#define FUSED_INST_3(...)
+static const ChainEntry kChainTable[] = {
+#include "fh_fused_instances.inc"
+};
+#undef FUSED_INST_0
+#undef FUSED_INST_1
+#undef FUSED_INST_2
+#undef FUSED_INST_3
+
 // the set-up kernel's variants: the same scheme, fh_setup_instances.inc / fh_setup_part.hip
 #ifndef FH_SINGLE_TU
 #define FH_SETUP_DECLARE(P, PI, T, NT, NR) extern template __global__ void k_setup_dense<P, PI, T, NT, NR>(const SetupP);
@@ -212,6 +239,7 @@ extern "C" int fh_destroy(fh_ctx* c) {
   free_operator(c);
   if (c->run_st_host) (void)hipHostFree(c->run_st_host);
   if (c->run_hist) (void)hipHostFree(c->run_hist);
+  if (c->chain_state) (void)hipFree(c->chain_state);
   if (c->gridbar) (void)hipFree(c->gridbar);
   if (c->lvl_rec) (void)hipFree(c->lvl_rec);
   if (c->lvl_cnt) (void)hipFree(c->lvl_cnt);
@@ -319,6 +347,8 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       if (value < 0 || value > 65536) return fail(FH_E_ARG, "FUSED_CUS must be in [0, 65536] (0 = every CU the device reports)");
       if ((int)value != c->fused_cus) { c->fused_cus = (int)value; c->coresident = -1; c->slots_sig = 0; }
       return 0;
+    case FH_TUNE_RUN_CHAIN:
+      c->run_chain_on = value ? 1 : 0; return 0;
     case FH_TUNE_SEQ_POLL:
       c->seq_poll = value ? 1 : 0; return 0;
     case FH_TUNE_RUN_MAX_N:
@@ -1022,11 +1052,24 @@ static const RunEntry* run_entry(fh_ctx* c) {
   for (const RunEntry& e : kRunTable) if (e.ppt >= need) return &e;
   return nullptr;
 }
+// The chained form (k_fused_chain, csrc/fh_fused.h) can serve what the persistent launch does not: float64 shapes of 1 / 2 / 4 team members
+// (n <= 16384) outside fh_run's window -- same prox kinds, single context.  OPT-IN (FH_TUNE_RUN_CHAIN = 1): it removes the gap between two
+// launches altogether (rocprofv3: 0.0 us against 11.6 us host-driven) but each launch is 5-7 us longer (the dependent dispatch, the state
+// block's way in, the controller), which is what the host-side loop with its sequence-number wait costs too -- 8192^2: 116.9 vs 115.6 us per
+// iteration, 16384^2: 351.6 vs 352.2 (profiles/r06_chain.txt).  The floor of DEPENDENT launches is the hardware's, not the host's.
+static bool chain_ok(fh_ctx* c) {
+  if (c->op != OP_DENSE || c->f32 || row_sharded(c) || !c->shards.empty() || !c->run_chain_on) return false;
+  if (c->prox_kind != FH_PROX_IDENTITY && c->prox_kind != FH_PROX_SHRINK && c->prox_kind != FH_PROX_NONNEG && c->prox_kind != FH_PROX_BOX) return false;
+  const FusedShape sh = fused_shape(c);
+  return sh.ppt && sh.team <= 4 && !sh.xlds && chain_lookup(sh, 0) != nullptr;
+}
 extern "C" int fh_run_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
-  *yes = (run_entry(c) && co_resident(c)) ? 1 : 0;
+  *yes = ((run_entry(c) || chain_ok(c)) && co_resident(c)) ? 1 : 0;
   return 0;
 }
+static int run_adopt(fh_ctx* c, const fh_run_opts* o, const RunState* hs, double* const (&nb)[5], int max_steps, fh_run_state* state, double* history, int* steps_done, const char* what);
+static int run_chain(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_state* state, double* history, int* steps_done);
 extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_state* state, double* history, int* steps_done) {
   FH_TRY(check_ready(c, true));
   if (!o || !state || !history || !steps_done) return fail(FH_E_ARG, "fh_run: null argument");
@@ -1034,11 +1077,12 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   if (o->window < 1 || o->window > FH_RUN_WINDOW_MAX) return fail(FH_E_ARG, "fh_run: window must be in [1, %d]", FH_RUN_WINDOW_MAX);
   if (o->stop_rule < 0 || o->stop_rule > 3) return fail(FH_E_ARG, "fh_run: stop_rule must be 0..3 (the four rules of fasta/stopping.py)");
   const RunEntry* e = run_entry(c);
+  if (!e && chain_ok(c) && co_resident(c)) return run_chain(c, max_steps, o, state, history, steps_done);
   if (!e || !co_resident(c)) return fail(FH_E_STATE, "fh_run: no device-side loop for this operator / loss / prox (see fh_run_supported)");
   FH_TRY(use_device(c));
   FH_TRY(not_lazy(c, "fh_run"));
   if (!c->run_st_host) {
-    HIP_TRY(hipHostMalloc(&c->run_st_host, sizeof(RunState), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(&c->run_st_host, 2 * sizeof(ChainState), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(&c->run_st_host_dev, c->run_st_host, 0));
   }
   if ((size_t)max_steps > c->run_hist_steps) {
@@ -1090,8 +1134,14 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   t_end(c, FH_K_FUSED);
   HIP_TRY(hipGetLastError());
   FH_TRY(finish(c));
-  hs = (RunState*)c->run_st_host;                       // the state on exit, written by the launch
-  // what the launch wrote back is checked before a single index of it is used: the block was poisoned (0xFF) before the launch
+  return run_adopt(c, o, (const RunState*)c->run_st_host, nb, max_steps, state, history, steps_done, "the persistent launch");
+}
+
+// What a device-side loop wrote back -- fh_run's persistent launch, or the last launch of a chain -- is checked before a single index of it
+// is used (the block was poisoned before the launch) and then adopted: buffer roles and indices exactly as fh_commit would have left them.
+// After a timeout (stopped == 3) that is the state of the last COMPLETED iteration: an attempt writes only buffers that are not x0 / g0 /
+// x_accel0 / z_accel0, so everything the next iteration reads is intact, and tau_next is the step the interrupted iteration began with.
+static int run_adopt(fh_ctx* c, const fh_run_opts* o, const RunState* hs, double* const (&nb)[5], int max_steps, fh_run_state* state, double* history, int* steps_done, const char* what) {
   {
     bool sane = (hs->stopped == 0 || hs->stopped == 1 || hs->stopped == 3) && hs->iteration >= state->iteration &&
                 hs->iteration - state->iteration <= (uint64_t)max_steps && hs->backtracks >= state->backtracks &&
@@ -1101,12 +1151,9 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
     for (int q = 0; q < 5 && sane; ++q) { if (hs->perm[q] < 0 || hs->perm[q] >= 5) sane = false; else seen |= 1u << hs->perm[q]; }
     if (!sane || seen != 31u) {
       c->slots_sig = 0;
-      return fail(FH_E_STATE, "fh_run: the persistent launch did not write a valid solver state back (stopped = %d) -- the state is undefined; call fh_init", hs->stopped);
+      return fail(FH_E_STATE, "fh_run: %s did not write a valid solver state back (stopped = %d) -- the state is undefined; call fh_init", what, hs->stopped);
     }
   }
-  // adopt the state the launch left: buffer roles and indices exactly as fh_commit would have left them.  After a grid-barrier timeout
-  // (stopped == 3) that is the state of the last COMPLETED iteration: an attempt writes only buffers that are not x0 / g0 / x_accel0 /
-  // z_accel0 (csrc/fh_run.h), so everything the next iteration reads is intact, and tau_next is the step the interrupted iteration began with.
   double* nx[5];
   for (int q = 0; q < 5; ++q) nx[q] = nb[hs->perm[q]];
   c->X[0] = nx[0]; c->X[1] = nx[1]; c->X[2] = nx[2]; c->P[0] = nx[3]; c->P[1] = nx[4];
@@ -1125,10 +1172,66 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
     // that attempt's z target -- the completed iteration's z_accel0, which only FISTA reads -- are overwritten.  z_accel0 = A x_accel0: form it again.
     if (o->accelerate) FH_TRY(op_fwd(c, 1, 0.0, c->P[c->pc], nullptr, nullptr, nullptr, nullptr, c->Z[c->zc], 0));
     FH_TRY(finish(c));
-    return fail(FH_E_TIMEOUT, "fh_run: a grid barrier of the persistent launch timed out after %d completed iterations (workgroups not co-resident?); "
-                              "the state of the last completed iteration is in place -- continue with fh_iterate / fh_step", done);
+    return fail(FH_E_TIMEOUT, "fh_run: a grid barrier / team hand-off of %s timed out after %d completed iterations (workgroups not co-resident?); "
+                              "the state of the last completed iteration is in place -- continue with fh_iterate / fh_step", what, done);
   }
   return 0;
+}
+
+// fh_run by a CHAIN of one-pass launches (csrc/fh_fused.h: k_fused_chain): the state goes to a device block, max_steps launches are enqueued back to
+// back -- each one attempt: it reads its step size and buffer roles from the block, its finaliser runs the controller and rewrites the block; launches
+// behind the stop rule, the step budget or a timeout return at once -- then the block comes back in one copy and is adopted as after the persistent launch.
+static int run_chain(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_state* state, double* history, int* steps_done) {
+  FH_TRY(use_device(c));
+  FH_TRY(not_lazy(c, "fh_run"));
+  if (!c->run_st_host) {
+    HIP_TRY(hipHostMalloc(&c->run_st_host, 2 * sizeof(ChainState), hipHostMallocMapped));     // [0]: what goes up, [1]: what comes back
+    HIP_TRY(hipHostGetDevicePointer(&c->run_st_host_dev, c->run_st_host, 0));
+  }
+  if (!c->chain_state) HIP_TRY(hipMalloc((void**)&c->chain_state, sizeof(ChainState)));
+  if ((size_t)max_steps > c->run_hist_steps) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->run_hist) { HIP_TRY(hipHostFree(c->run_hist)); c->run_hist = nullptr; c->run_hist_steps = 0; }
+    const size_t steps = round_up((size_t)max_steps, 256);
+    HIP_TRY(hipHostMalloc((void**)&c->run_hist, steps * FR_HIST * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->run_hist_dev, c->run_hist, 0));
+    c->run_hist_steps = steps;
+  }
+  ChainState* hst = (ChainState*)c->run_st_host;
+  memset(hst, 0, sizeof(ChainState));
+  RunState* hs = &hst->rs;
+  hs->tau_next = state->tau_next; hs->alpha1 = state->alpha1; hs->max_residual = state->max_residual; hs->best_quality = state->best_quality;
+  hs->iteration = state->iteration; hs->backtracks = state->backtracks; hs->stopped = 0;
+  hs->xi = c->xi; hs->ti = c->ti; hs->bi = c->bi; hs->pc = c->pc; hs->gc = c->gc; hs->zc = c->zc; hs->last_accel = c->last_accel ? 1 : 0;
+  for (int q = 0; q < 5; ++q) hs->perm[q] = q;
+  memcpy(hs->f_window, state->f_window, sizeof(hs->f_window));
+  hst->tau_iter = state->tau_next;
+  HIP_TRY(hipMemcpyAsync(c->chain_state, hst, sizeof(ChainState), hipMemcpyHostToDevice, c->stream));
+  double* nb[5] = {c->X[0], c->X[1], c->X[2], c->P[0], c->P[1]};
+  ChainP ch;
+  for (int q = 0; q < 5; ++q) ch.nbuf[q] = nb[q];
+  ch.G[0] = c->G[0]; ch.G[1] = c->G[1]; ch.Z[0] = c->Z[0]; ch.Z[1] = c->Z[1];
+  ch.mu = c->mu;
+  ch.o.adaptive = o->adaptive; ch.o.accelerate = o->accelerate; ch.o.backtrack = o->backtrack; ch.o.restart = o->restart;
+  ch.o.evaluate_objective = o->evaluate_objective; ch.o.stop_rule = o->stop_rule; ch.o.window = o->window; ch.o.max_backtracks = o->max_backtracks;
+  ch.o.stepsize_shrink = o->stepsize_shrink; ch.o.tolerance = o->tolerance;
+  ch.g_kind = c->prox_kind == FH_PROX_SHRINK ? 1 : 0;
+  ch.max_steps = max_steps;
+  ch.st = (ChainState*)c->chain_state;
+  ch.hist = c->run_hist_dev;
+  // (operands the launch takes from the state block are placeholders here; xhat is the one n-side buffer whose role never changes)
+  FusedIO fio = {c->X[c->xi], c->G[c->gc], c->xhat, c->P[c->pc ^ 1], c->Z[c->zc ^ 1], c->G[c->gc ^ 1], c->prox_kind, 0};
+  c->seq_wait = 0;
+  const bool timed = t_on(c, FH_K_FUSED);
+  if (timed) t_begin(c, FH_K_FUSED);                       // ONE event pair around the chain: records between dependent launches would serialise the host with them
+  for (int j = 0; j < max_steps; ++j) FH_TRY(launch_fused_dense(c, 0.0, fio, &ch));
+  if (timed) t_end(c, FH_K_FUSED);
+  ChainState* back = hst + 1;
+  memset(back, 0xFF, sizeof(ChainState));                 // (poisoned: a copy that never landed cannot pass for a state)
+  HIP_TRY(hipMemcpyAsync(back, c->chain_state, sizeof(ChainState), hipMemcpyDeviceToHost, c->stream));
+  FH_TRY(finish(c));
+  if (timed && back->attempts > 1 && back->attempts <= max_steps) c->launches[FH_K_FUSED] += (uint64_t)(back->attempts - 1);     // the pair timed `attempts` launches (+ the no-op ones, ~4 us each)
+  return run_adopt(c, o, &back->rs, nb, max_steps, state, history, steps_done, "a chained one-pass launch");
 }
 
 // How often this context recovered from an in-launch timeout: what = 0 level searches that fell back to one workgroup, 1 level searches

@@ -223,6 +223,8 @@ struct fh_ctx {
   double* lvl_rec = nullptr;         // multi-workgroup level search: per-pass records and counters (allocated on first use, counters kept zero)
   unsigned* lvl_cnt = nullptr;
   double* selftest_buf = nullptr;    // fh_comm_selftest's scratch (freed before it returns)
+  void* chain_state = nullptr;       // device block of the chained form of fh_run (csrc/fh_fused.h: ChainState)
+  int run_chain_on = 0;              // FH_TUNE_RUN_CHAIN = 1: outside the persistent launch's window fh_run takes the chained form (opt-in: measured equal to the host-side loop)
   uint64_t run_timeouts = 0;         // persistent launches of fh_run that ended in a grid-barrier timeout (fh_recovered_count)
   bool pending_step = false;         // fh_step_begin has issued a step whose fh_step_end is still to come (every other entry point refuses)
   bool emulated = false;             // shell / shard: the device ids repeat (one device, one stream, k_sum_shards)

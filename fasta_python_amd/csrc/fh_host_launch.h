@@ -405,7 +405,14 @@ struct FusedIO {
 // after the synchronisation that follows a one-pass launch: a launch that timed out has left slots un-posted / un-armed
 static inline void fused_after(fh_ctx* c) { if (c->hscal[15] != 0.0) c->slots_sig = 0; }
 
-static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
+static const ChainEntry* chain_lookup(const FusedShape& sh, int f32) {
+  for (const ChainEntry& e : kChainTable)
+    if (e.ppt == sh.ppt && e.pipe == sh.pipe && e.team == sh.team && e.xlds == sh.xlds && e.nbo == sh.nbo && e.f32 == f32) return &e;
+  return nullptr;
+}
+// chain != nullptr: the CHAINED form (k_fused_chain): tau and the solver-state pointers of `io` are placeholders, the launch takes them
+// from chain->st; no per-launch event records (the caller brackets the whole chain) and no sequence number (nobody waits for a single launch)
+static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io, const ChainP* chain = nullptr) {
   const FusedShape sh = fused_shape(c);
   if (!sh.ppt) return fail(FH_E_STATE, "fused one-pass step: unsupported operator shape (needs a dense A with n <= 262144 and a scalar-separable prox)");
   const FusedEntry* k_fused_dense_entry = fused_lookup(sh, c->f32);
@@ -448,7 +455,9 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
   p.out = scalar_out(c);
-  t_begin(c, FH_K_FUSED);
+  const ChainEntry* chain_entry = chain ? chain_lookup(sh, c->f32) : nullptr;
+  if (chain && !chain_entry) return fail(FH_E_STATE, "chained one-pass launch: no instantiation for this shape (teams of 1 / 2 / 4 members, float64)");
+  if (!chain) t_begin(c, FH_K_FUSED);
   {
     // signature of everything the slot layout depends on; 0 = "refill" (set after a timed-out launch, see fused_after)
     uint64_t sig = fh_mix((uint64_t)(uintptr_t)c->slotbuf ^ fh_mix(slots_elems * 131 + (uint64_t)sh.team * 7 + p.nteams)) | 1ull;
@@ -464,6 +473,12 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io) {
     p.slots = c->slotbuf + (size_t)c->slots_parity * slots_elems;
     p.slots_next = c->slotbuf + (size_t)(c->slots_parity ^ 1) * slots_elems;
     c->slots_parity ^= 1;
+  }
+  if (chain) {
+    p.px.seq = 0u;
+    chain_entry->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p, *chain);
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
   p.px.seq = io.mode == 0 ? seq_offer(c) : 0u;
   k_fused_dense_entry->kernel<<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);

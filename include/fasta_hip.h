@@ -112,6 +112,10 @@ enum fh_tuning_key {
                                 rows; 0 = the measured window (profiles/r06_device_loop.txt): n <= 4096 up to 32 Mi elements, n <= 6144 from 4096 rows
                                 on up to 40 Mi elements -- elsewhere one launch per iteration issued by fh_iterate is as fast or faster; at most
                                 7168 = the widest row it has a kernel for                                                          */
+  FH_TUNE_RUN_CHAIN = 19,    /* 0 (default) / 1: outside the persistent launch's window fh_run takes the CHAINED form where it exists (float64, n <= 16384,
+                                separable prox: max_steps one-pass launches enqueued back to back, step size and buffer roles from a device state
+                                block, the loop's controller in each launch's finaliser).  Opt-in: measured equal to the host-side loop
+                                (profiles/r06_chain.txt) -- the gap between launches disappears, the launches grow by as much             */
   FH_TUNE_SEQ_POLL = 18,     /* 1 (default): a single-device step waits for its scalar block by the sequence number the launch writes behind
                                 it into host-mapped memory (~5 us sooner than the launch's completion signal); 0: hipStreamSynchronize (A/B)  */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device

@@ -12,6 +12,10 @@ if len(sys.argv) > 2:
     sizes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
 iters = 1024
 tuning = {hip.TUNE_RUN_MAX_N: 7168}
+if os.environ.get("FH_RUN_CHAIN") == "1":          # the chained form of fh_run outside the persistent launch's window (opt-in)
+    tuning[hip.TUNE_RUN_CHAIN] = 1
+    tuning.pop(hip.TUNE_RUN_MAX_N)
+    print("# FH_TUNE_RUN_CHAIN = 1, default window of the persistent launch: the device column is the chain of one-pass launches outside it")
 if os.environ.get("FH_SEQ_POLL") == "0":          # A/B: wait for every launch with hipStreamSynchronize (rounds 1-5) instead of its sequence number
     tuning[hip.TUNE_SEQ_POLL] = 0
     print("# FH_TUNE_SEQ_POLL = 0: hipStreamSynchronize after every launch")

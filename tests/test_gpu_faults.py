@@ -187,3 +187,35 @@ def test_fh_run_reports_the_timeout_with_a_typed_status_and_the_completed_histor
         np.testing.assert_allclose(c.get_vector(hip.VEC_X0, n), x_ref, rtol=1e-6, atol=1e-10)
     finally:
         op.close()
+
+
+def test_a_hand_off_timeout_inside_a_chain_of_launches_keeps_the_solve():
+    """The chained form of the device loop (opt-in, FH_TUNE_RUN_CHAIN; k_fused_chain): a team member withholds its first partial in EVERY launch
+    (fault-injection bit 1), so the first launch of the chain reports a hand-off timeout -- its finaliser marks the state `stopped = 3`, the
+    rest of the chain returns at once, the host adopts the (unchanged) state and the driver carries on with the library loop, whose
+    one-pass launches time out the same way and fall back to K-fwd / K-adj.  The solve must equal the two-launch solve."""
+    rng = np.random.RandomState(2)
+    m, n = 96, 8192
+    A = rng.randn(m, n) / 40
+    b = rng.randn(m)
+    ls, reg = fa.LeastSquares(b), fa.Shrink(0.02)
+    opts = dict(verbose=False, backend="hip", tolerance=1e-6, max_iters=12, evaluate_objective=True)
+    op = fa.DenseMatrixMap(A, tuning={hip.TUNE_RUN_CHAIN: 1})
+    try:
+        np.random.seed(4)
+        ref = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), fused=False, **opts)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, hip.HOOK_WITHHOLD_PARTIAL)
+        np.random.seed(4)
+        with pytest.warns(UserWarning) as rec:
+            got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, np.zeros(n), device_iters=8, **opts)
+        op.ctx.set_tuning(hip.TUNE_TEST_HOOKS, 0)
+        assert op.ctx.recovered_count(hip.RECOVERED_RUN_TIMEOUT) == 1
+    finally:
+        op.close()
+    text = " | ".join(str(w.message) for w in rec)
+    assert "fh_run" in text and "timed out" in text and "one-pass kernel disabled" in text
+    assert got.device_steps == 0 and got.library_steps == got.iteration_count == ref.iteration_count
+    k = got.iteration_count
+    np.testing.assert_allclose(got.residuals[:k], ref.residuals[:k], rtol=1e-12)
+    np.testing.assert_allclose(got.solution, ref.solution, rtol=1e-12, atol=1e-15)
+
