@@ -1224,11 +1224,22 @@ static int run_chain(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_stat
   c->seq_wait = 0;
   const bool timed = t_on(c, FH_K_FUSED);
   if (timed) t_begin(c, FH_K_FUSED);                       // ONE event pair around the chain: records between dependent launches would serialise the host with them
-  for (int j = 0; j < max_steps; ++j) FH_TRY(launch_fused_dense(c, 0.0, fio, &ch));
-  if (timed) t_end(c, FH_K_FUSED);
   ChainState* back = hst + 1;
-  memset(back, 0xFF, sizeof(ChainState));                 // (poisoned: a copy that never landed cannot pass for a state)
-  HIP_TRY(hipMemcpyAsync(back, c->chain_state, sizeof(ChainState), hipMemcpyDeviceToHost, c->stream));
+  // One launch = one attempt, so max_steps launches complete max_steps iterations only when nothing backtracks.  The call never returns in the
+  // MIDDLE of an iteration (its retries so far and the step it began with live in the device block only): while the block says "retrying", the
+  // launches the remaining budget allows are enqueued on top -- the block stays where it is, only its copy comes back.  That is also what makes
+  // the solve independent of the chain length (K = 1: every chain is one attempt).
+  for (int enqueue = max_steps;;) {
+    for (int j = 0; j < enqueue; ++j) FH_TRY(launch_fused_dense(c, 0.0, fio, &ch));
+    if (timed) t_end(c, FH_K_FUSED);
+    memset(back, 0xFF, sizeof(ChainState));               // (poisoned: a copy that never landed cannot pass for a state)
+    HIP_TRY(hipMemcpyAsync(back, c->chain_state, sizeof(ChainState), hipMemcpyDeviceToHost, c->stream));
+    if (timed) { const int keep = c->ev_cur[FH_K_FUSED]; c->ev_pending[FH_K_FUSED][keep] = false; }       // (harvested below, once, after the last round)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (back->rs.stopped != 0 || back->bt <= 0 || back->steps_done < 0 || back->steps_done >= max_steps) break;
+    enqueue = max_steps - back->steps_done;
+  }
+  if (timed) c->ev_pending[FH_K_FUSED][c->ev_cur[FH_K_FUSED]] = true;
   FH_TRY(finish(c));
   if (timed && back->attempts > 1 && back->attempts <= max_steps) c->launches[FH_K_FUSED] += (uint64_t)(back->attempts - 1);     // the pair timed `attempts` launches (+ the no-op ones, ~4 us each)
   return run_adopt(c, o, &back->rs, nb, max_steps, state, history, steps_done, "a chained one-pass launch");
