@@ -659,17 +659,14 @@ extern "C" int fh_init(fh_ctx* c, double* scalars) {
 // enough for the one-pass kernel to pay) all of it comes from ONE read of A; everywhere else -- and after a hand-off timeout -- it is
 // the three passes fh_gradient_at x 2 + fh_init, so the call is always available and its results agree to summation-order rounding
 // (bit for bit where the one-pass kernel serves the three passes too).
-static int launch_setup_dense(fh_ctx* c, bool* launched) {
+static const SetupEntry* setup_entry(fh_ctx* c);
+// sharded = true: a row block (shard of a multi-device context, or a rank): scalars to device memory, partial sums in T[2] / G[gc], pack behind T[2]
+static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
   *launched = false;
-  if (c->op != OP_DENSE || c->f32 || c->loss_kind != LOSS_LSQ || row_sharded(c) || !c->shards.empty() || !fused_pays(c)) return 0;
-  const FusedShape sh = fused_shape(c);
-  if (!sh.ppt || sh.xlds) return 0;
-  const SetupEntry* e = nullptr;
-  // full 8-piece shapes of 8 / 16 members: 512-thread workgroups (fh_setup_instances.inc); FH_TUNE_FUSED_VARIANT bit 16 keeps the 256-thread form (A/B)
-  const int want_threads = (sh.ppt == 8 && sh.team >= 8 && sh.team <= 16 && !(c->fused_variant & 16)) ? 512 : 256;
-  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe) && k.threads == want_threads) { e = &k; break; }
-  if (!e && want_threads == 512) for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) { e = &k; break; }
+  if (!sharded && (row_sharded(c) || !c->shards.empty())) return 0;
+  const SetupEntry* e = setup_entry(c);
   if (!e || !co_resident(c)) return 0;
+  const FusedShape sh = fused_shape(c);
   SetupP p;
   p.A = c->A; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
   p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.ldp = (uint32_t)(c->ld / 2); p.nv2 = p.ld2;
@@ -703,6 +700,7 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);
+  p.pack = sharded ? c->T[2] + c->nv : nullptr;     // (slack behind every n-side vector: alloc_vectors)
   t_begin(c, FH_K_FUSED);
   e->kernel<<<dim3(grid), dim3(e->threads), 0, c->stream>>>(p);
   t_end(c, FH_K_FUSED);
@@ -711,11 +709,83 @@ static int launch_setup_dense(fh_ctx* c, bool* launched) {
   return 0;
 }
 
+// the one-read set-up kernel of this context's shape, or nullptr (the three passes then): dense float64 least squares, n <= 65536, large enough to pay
+static const SetupEntry* setup_entry(fh_ctx* c) {
+  if (c->op != OP_DENSE || c->f32 || c->loss_kind != LOSS_LSQ || !fused_pays(c)) return nullptr;
+  const FusedShape sh = fused_shape(c);
+  if (!sh.ppt || sh.xlds) return nullptr;
+  // full 8-piece shapes of 8 / 16 members: 512-thread workgroups (fh_setup_instances.inc); FH_TUNE_FUSED_VARIANT bit 16 keeps the 256-thread form (A/B)
+  const int want_threads = (sh.ppt == 8 && sh.team >= 8 && sh.team <= 16 && !(c->fused_variant & 16)) ? 512 : 256;
+  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe) && k.threads == want_threads) return &k;
+  if (want_threads == 512) for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) return &k;
+  return nullptr;
+}
+
 static int diff_norm_sq(fh_ctx* c, int vec_a, int vec_b, double* sumsq);
 extern "C" int fh_gradient_at(fh_ctx* c, int src_vec, int dst_vec);
+
+// The one-read set-up over ROW BLOCKS (round 6): least squares is linear in the rows, so every block runs the two-right-hand-side kernel on its
+// own rows -- A_k^T A_k (x1 - x2) into T[2], A_k^T (A_k x0 - b_k) into g0, z_k = A_k x0, its loss sum -- and ONE exchange sums both n-vectors
+// with the loss sums and the timeout words riding behind the first (as a step's n + 3 exchange does); ||sum_k A_k^T A_k d||^2 is then one small
+// reduction on replicated data.  One launch per block instead of three.  *done = false: not taken (a block has no shape for it, the ranks do
+// not agree, a hand-off timed out somewhere -- every block then sees the same summed timeout word): the caller runs the three passes.
+// Ranks of a communicator settle the decision first (fh_fused_agree is collective: every rank is inside fh_setup at this point).
+static int setup_row_blocks(fh_ctx* c, double* scalars, bool* done) {
+  *done = false;
+  const int ns = nshards(c);
+  bool all = true;
+  for (int k = 0; k < ns; ++k) { fh_ctx* s = shard_of(c, k); if (!setup_entry(s) || (c->shards.empty() ? false : !co_resident(s))) all = false; }
+  if (c->shards.empty()) {              // a rank: the verdict of ALL ranks (1 = the one-pass kernel is available and recommended everywhere)
+    int kind = 0;
+    FH_TRY(fh_fused_agree(c, &kind));
+    if (kind != 1) all = false;
+  }
+  if (!all) return 0;
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    FH_TRY(use_device(s));
+    bool launched = false;
+    FH_TRY(launch_setup_dense(s, &launched, true));
+    if (!launched) return fail(FH_E_STATE, "fh_setup: a row block lost its one-read set-up kernel between the check and the launch");
+  }
+  FH_TRY(sum_over_shards(c, [](fh_ctx* s) { return s->T[2]; }, (size_t)shard_of(c, 0)->nv + 2, [](fh_ctx* s) { return s->G[s->gc]; }, (size_t)shard_of(c, 0)->nv));
+  for (int k = 0; k < ns; ++k) {
+    fh_ctx* s = shard_of(c, k);
+    FH_TRY(use_device(s));
+    s->lazy = false; s->commits = 0; s->tvz_pending = false; s->zcur_stale = false;
+    double* x0 = s->X[s->xi];
+    HIP_TRY(hipMemcpyAsync(s->P[s->pc], x0, s->nv * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    s->bi = s->xi;
+    for (int q = 0; q < 3; ++q) if (q != s->xi) { s->ti = q; break; }
+    s->last_accel = false;
+    s->slots_sig = 0;                   // (the set-up kernel's slots share the step kernel's buffer)
+    FH_TRY(launch_gterms(s, x0));
+  }
+  // ||sum_k A_k^T A_k d||^2 on block 0 (replicated data), and the summed loss / timeout words from behind T[2]
+  fh_ctx* s0 = shard_of(c, 0);
+  FH_TRY(use_device(s0));
+  HIP_TRY(hipMemsetAsync(s0->T[3], 0, s0->nv * sizeof(double), s0->stream));
+  double dg2 = 0.0;
+  FH_TRY(diff_norm_sq(s0, FH_VEC_T2, FH_VEC_T3, &dg2));
+  HIP_TRY(hipMemcpyAsync(s0->hscal + FH_NSCALARS + 2, s0->T[2] + s0->nv, 2 * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
+  FH_TRY(fetch_scalars(c, scalars));
+  const double fsq = s0->hscal[FH_NSCALARS + 2], timed_out = s0->hscal[FH_NSCALARS + 3];
+  if (timed_out != 0.0) return 0;       // (summed over the blocks: every block / rank comes to the same conclusion)
+  scalars[FH_S_FSQ] = fsq;
+  scalars[FH_S_DG2] = dg2;
+  scalars[15] = 0.0;
+  *done = true;
+  return 0;
+}
+
 extern "C" int fh_setup(fh_ctx* c, double* scalars) {
   FH_TRY(check_ready(c, true));
   if (!scalars) return fail(FH_E_ARG, "fh_setup: null scalars");
+  if (!c->shards.empty() || c->comm) {
+    bool done = false;
+    FH_TRY(setup_row_blocks(c, scalars, &done));
+    if (done) return 0;
+  }
   if (c->shards.empty()) {
     bool launched = false;
     FH_TRY(use_device(c));

@@ -18,8 +18,9 @@
 //   * the finaliser also forms ||A^T A d||^2 and (team 0's prologue) ||x1 - x2||^2: the two norms of :110 come back with the scalar
 //     block, no further launch.
 // Shapes: float64 storage, PPT <= 8 (n <= 65536): NR x PPT x 4 KiB of LDS for the x slices, NR x PPT x 4 registers for the gradient
-// slices.  Wider rows, float32 storage, the logistic loss and row-sharded contexts keep the three-pass set-up (fh_setup falls back by
-// itself).  The slots are filled with the sentinel by the host before the launch (one launch per solve: no re-arming).
+// slices.  Wider rows, float32 storage and the logistic loss keep the three-pass set-up (fh_setup falls back by itself).  Row blocks
+// (round 6: a multi-device context, or a rank of a row-sharded run) launch it per block -- it is linear in the rows like least squares
+// itself -- and sum A_k^T A_k d, the gradients and the loss sums in ONE exchange (csrc/fasta_hip.hip:setup_row_blocks).  The slots are filled with the sentinel by the host before the launch (one launch per solve: no re-arming).
 #pragma once
 #include "fh_fused.h"
 
@@ -41,6 +42,8 @@ struct SetupP {
   unsigned* err;
   int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls (as FusedP.variant)
   double* out;                 // scalar block: [S_FSQ] loss sum at x0, [S_DX2] ||x1 - x2||^2, [S_DG2] ||grad1 - grad2||^2, [15] timeout
+  double* pack;                // optional (row blocks, round 6): 2 doubles behind g[0] -- this block's loss sum and its timeout word -- so that the ONE sum
+                               // over the row blocks of A_k^T A_k d carries them along; g[0], g[2] then hold this block's PARTIAL sums and [S_DG2] is void
 };
 
 // sum of NW wave partials in wave order (NW = 4: the order of k_fused_dense)
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
     for (int k = 0; k < 16; ++k) p.out[k] = 0.0;
     p.out[S_FSQ] = w[0]; p.out[S_DX2] = w[1]; p.out[S_DG2] = w[2];
     p.out[15] = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0 : 0.0;
+    if (p.pack) { p.pack[0] = w[0]; p.pack[1] = p.out[15]; }
     __hip_atomic_store(p.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(p.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -171,3 +171,71 @@ def test_full_solve_through_the_one_read_set_up_matches_the_oracle(mode):
     np.testing.assert_allclose(got.stepsizes[:k], want.stepsizes[:k], rtol=1e-8)
     np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
     np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("blocks", [2, 4, 8])
+@pytest.mark.parametrize("rows_per_block,n", [(2100, 4096), (1100, 8192), (80, 16384), (40, 40000), (30, 65536)])
+def test_row_blocks_take_one_read_of_A_each_for_the_set_up(rows_per_block, n, blocks):
+    """Round 6: least squares is linear in the rows, so a multi-device context (here: all blocks on the one GPU) launches the two-right-hand-side
+    kernel once per row block and sums A_k^T A_k (x1 - x2), the gradients and the loss sums in ONE exchange -- instead of K-fwd + K-adj three
+    times per block (six reads of A).  g0 / z / f agree with that to summation-order rounding, L to rtol 1e-12, and against NumPy; the first step
+    after the one-read set-up equals the first step after fh_init."""
+    m = rows_per_block * blocks
+    rng = np.random.RandomState(m + n + blocks)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    op = fa.ShardedDenseMatrixMap(A, devices=[0] * blocks)
+    try:
+        c = op.ctx
+        assert c.fused_supported() == 1
+        p1, p2, x0 = _load(c, rng, m, n, "lsq")
+        want = _three_pass(c, n, m)
+        passes_before = (c.timing_get(hip.K_FWD)[1], c.timing_get(hip.K_ADJ)[1])      # row blocks took K-fwd + K-adj for each of the three: SIX reads of A per block
+        for which, v in ((hip.VEC_T2, np.zeros(n)), (hip.VEC_T3, np.zeros(n))):
+            c.set_vector(which, v)
+        c.set_vector(hip.VEC_X0, x0)
+        got = _one_call(c, n, m)
+        assert want["one_pass_launches"] == 0 and passes_before == (3 * blocks, 3 * blocks)
+        assert got["one_pass_launches"] == blocks and (c.timing_get(hip.K_FWD)[1], c.timing_get(hip.K_ADJ)[1]) == (0, 0)      # ... now ONE
+        wide = 28672 < n <= 32768 or 57344 < n <= 65536
+        for key in ("g0", "z"):                                     # (K-fwd / K-adj sum in another order than the one-read kernel)
+            np.testing.assert_allclose(got[key], want[key], rtol=1e-11, atol=1e-13 * np.abs(want[key]).max(), err_msg=key)
+        np.testing.assert_allclose([got["s"][k] for k in (hip.S_GSUM, hip.S_GMAX, hip.S_FSQ)], [want["s"][k] for k in (hip.S_GSUM, hip.S_GMAX, hip.S_FSQ)], rtol=1e-12)
+        b = c.get_vector(hip.VEC_B, m)
+        np.testing.assert_allclose(got["s"][hip.S_FSQ], np.sum((A @ x0 - b) ** 2), rtol=1e-11)
+        np.testing.assert_allclose(got["t2"], A.T @ (A @ (p1 - p2)), rtol=1e-9, atol=1e-12 * np.abs(want["t2"]).max())
+        np.testing.assert_allclose([got["dg"], got["dx"]], [want["dg"], want["dx"]], rtol=1e-12)
+        np.testing.assert_allclose(got["g0"], A.T @ (A @ x0 - b), rtol=1e-9, atol=1e-12 * np.abs(want["g0"]).max())
+        for k in range(blocks):                                    # replicated vectors: the same on every block
+            shard, _, _ = c.shard(k)
+            assert np.array_equal(shard.get_vector(hip.VEC_G0, n), got["g0"])
+        s1 = c.step(0.3)
+        c.set_vector(hip.VEC_X0, x0)
+        c.init()
+        np.testing.assert_allclose(c.step(0.3)[:14], s1[:14], rtol=1e-9, atol=1e-13)
+    finally:
+        op.close()
+
+
+def test_full_solve_on_row_blocks_through_the_one_read_set_up_matches_the_oracle():
+    np.random.seed(2)
+    P = pr.sparse_least_squares(M=8400, N=4096, K=40)
+    opts = dict(tolerance=1e-6, max_iters=60, evaluate_objective=True)
+    np.random.seed(4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    ls, reg = fa.LeastSquares(P.data["b"]), fa.Shrink(P.data["mu"])
+    op = fa.ShardedDenseMatrixMap(P.data["A"], devices=[0, 0, 0, 0])
+    try:
+        op.ctx.timing_enable(True)
+        np.random.seed(4)
+        got = fa.fasta(op, ls.f, ls.gradf, reg.g, reg.prox, P.x0, verbose=False, backend="hip", **opts)
+        launches = op.ctx.timing_get(hip.K_FUSED)[1]
+    finally:
+        op.close()
+    k = want.iteration_count
+    assert got.iteration_count == k and got.backtracks == want.backtracks
+    assert launches == 4 * (1 + k + got.backtracks)                      # per block: ONE launch for the whole set-up, one per iteration / retry
+    np.testing.assert_allclose(got.residuals[:k], want.residuals[:k], rtol=1e-6)
+    np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-8)
+    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)
