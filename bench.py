@@ -1042,6 +1042,8 @@ def main(argv=None):
                     s = sub_result(r, f"LASSO {m_total}x{n} as 8 row blocks of {m_total // 8} rows driven from one process "
                                       f"(ShardedDenseMatrixMap, all blocks on this GPU, sums in block order by an in-library kernel)")
                     s["row_blocks"], s["comm_avg_ms"] = A8.ctx.comm_count(), r["comm_avg_ms"]
+                    # the natural run on the row blocks: its set-up is ONE launch of the two-right-hand-side kernel per block + one exchange (round 6)
+                    s["natural_run"] = natural_runs(A8, n, m_total)["lasso"]
                     extra["inproc_8_row_blocks"] = s
                 finally:
                     A8.close()
