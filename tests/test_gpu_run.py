@@ -238,3 +238,29 @@ def test_the_chain_length_does_not_change_a_single_bit(n):
             for f in ("residuals", "norm_residuals", "stepsizes", "solution"):
                 assert np.array_equal(getattr(r, f), getattr(runs[0], f)), f
 
+
+@pytest.mark.parametrize("mode", ["adaptive", "accelerated", "plain"])
+def test_full_length_histories_of_the_device_loop_against_the_oracle(mode):
+    """the random-problem tests above pin histories on the first 40 iterations.  Here the WHOLE solve, per mode, on a problem outside
+    the sensitive regime (overdetermined, m > n: SURVEY section 7 -- re-ordered sums stay within 1e-13 over entire solves there): every iteration of
+    every history at rtol 1e-6 against the oracle, to the stop rule's last iteration, through persistent launches of 16."""
+    rng = np.random.RandomState(77)
+    m, n = 1500, 1000
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    xt = np.zeros(n)
+    xt[rng.permutation(n)[:20]] = 1
+    b = A @ xt + 0.01 * rng.randn(m)
+    opts = dict(tolerance=1e-8, max_iters=400, evaluate_objective=True, **MODES[mode])
+    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=16, **opts)
+    P = pr.sparse_least_squares_from(A, b, 0.02)
+    np.random.seed(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = fo.fasta(*P.args7(), **opts)
+    k = want.iteration_count
+    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == want.backtracks and k > 60
+    for f in ("residuals", "norm_residuals", "stepsizes"):
+        np.testing.assert_allclose(getattr(dev, f)[:k], getattr(want, f)[:k], rtol=1e-6, atol=1e-300, err_msg=f)
+    np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-10)
+    np.testing.assert_allclose(dev.solution, want.solution, rtol=1e-6, atol=1e-12)
+
