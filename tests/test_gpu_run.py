@@ -250,15 +250,15 @@ def test_full_length_histories_of_the_device_loop_against_the_oracle(mode):
     xt = np.zeros(n)
     xt[rng.permutation(n)[:20]] = 1
     b = A @ xt + 0.01 * rng.randn(m)
-    opts = dict(tolerance=1e-8, max_iters=400, evaluate_objective=True, **MODES[mode])
-    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=16, **opts)
+    opts = dict(tolerance=1e-7, max_iters=400, evaluate_objective=True, **MODES[mode])
+    dev = _solve(A, b, fa.Shrink(0.02), np.zeros(n), device_iters=16, stop_rule=stopping.residual, **opts)      # (the absolute rule: runs on well past the hybrid rule's stop)
     P = pr.sparse_least_squares_from(A, b, 0.02)
     np.random.seed(5)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        want = fo.fasta(*P.args7(), **opts)
+        want = fo.fasta(*P.args7(), stop_rule=fo.residual, **opts)
     k = want.iteration_count
-    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == want.backtracks and k > 60
+    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == want.backtracks and 30 < k < 400
     for f in ("residuals", "norm_residuals", "stepsizes"):
         np.testing.assert_allclose(getattr(dev, f)[:k], getattr(want, f)[:k], rtol=1e-6, atol=1e-300, err_msg=f)
     np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-10)
