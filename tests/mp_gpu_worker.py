@@ -19,6 +19,7 @@ from fasta_python_amd import hip                # noqa: E402
 def main():
     out_dir, mode, m, n, fused = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     probe_no_rank = int(sys.argv[6]) if len(sys.argv) > 6 else -1     # this rank's co-residency probe is made to answer "no"
+    driver = sys.argv[7] if len(sys.argv) > 7 else "record"           # "record": record_iterates (Python between iterations); "library" / "python": that driver
     grp = bench.make_group(120.0)
     rng = np.random.RandomState(7)              # the same problem on every rank
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
@@ -38,7 +39,7 @@ def main():
     op.ctx.comm_init(grp.world, grp.rank, uid)
     assert op.ctx.comm_count() == grp.world and op.ctx.sharded
     ls, reg = fa.LeastSquares(b[lo:hi]), fa.Shrink(0.02)
-    opts = dict(tolerance=1e-7, evaluate_objective=True, record_iterates=True, max_iters=40, verbose=False,
+    opts = dict(tolerance=1e-7, evaluate_objective=True, record_iterates=(driver == "record"), max_iters=40, verbose=False,
                 adaptive=(mode != "fista"), accelerate=(mode == "fista"),
                 fused={"auto": "auto", "on": True, "off": False}[fused])
     if mode == "forced_backtracking":
@@ -48,7 +49,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
-            solver = fa.FBSolver(op, ls, reg, np.zeros(n), **opts).setup()
+            solver = fa.FBSolver(op, ls, reg, np.zeros(n), **opts, **({} if driver == "record" else dict(driver=driver, device_iters=7))).setup()
         except ValueError as exc:                  # fused=True without a one-pass kernel: must happen on EVERY rank or on none
             raised = str(exc)
     if raised:
@@ -61,7 +62,7 @@ def main():
             c = solver.run()
         comm_ms, comm_launches = op.ctx.timing_get(hip.K_COMM)      # exchanges of the loop alone
         np.savez(os.path.join(out_dir, f"rank{grp.rank}.npz"), residuals=c.residuals, stepsizes=c.stepsizes, objectives=c.objectives,
-                 iterates=c.iterates, solution=c.solution, iteration_count=c.iteration_count, backtracks=c.backtracks,
+                 iterates=c.iterates if c.iterates is not None else np.zeros(0), solution=c.solution, library_steps=c.library_steps, iteration_count=c.iteration_count, backtracks=c.backtracks,
                  fused_steps=solver.fused_steps, use_fused=int(solver.use_fused), solver_mode=str(solver.mode),
                  backoff=solver._fused_backoff, comm_launches=int(comm_launches), cus=np.array(op.ctx.cu_count()),
                  comm_library=hip.comm_library())

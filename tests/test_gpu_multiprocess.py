@@ -102,6 +102,27 @@ def test_real_processes_row_shard_a_solve_on_one_gpu(tmp_path, mock_rccl, world,
     np.testing.assert_allclose(r0["iterates"][:k + 1], want.iterates[:k + 1], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("world,mode,m,n", [(2, "adaptive", 256, 20000), (3, "fista", 300, 4096), (2, "forced_backtracking", 96, 160)])
+def test_every_rank_runs_the_library_loop_and_they_stay_in_step(tmp_path, mock_rccl, world, mode, m, n):
+    """Round 6: on a rank of a row-sharded run the loop is driven by fh_iterate too (the default) -- every rank calls it with the same arguments,
+    takes the same decisions from the all-reduced scalars and issues the same collectives.  Real rank processes (calls of 7 iterations) against
+    the same ranks driven by Python: EQUAL histories and solutions, on every rank; one-read set-up per row block where the shape has one."""
+    runs = {}
+    for driver in ("library", "python"):
+        out = tmp_path / driver
+        out.mkdir()
+        _run_ranks(world, [out, mode, m, n, "auto", -1, driver], mock_rccl)
+        runs[driver] = [np.load(out / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):
+        lib, py = runs["library"][r], runs["python"][r]
+        assert int(lib["library_steps"]) == int(lib["iteration_count"]) and int(py["library_steps"]) == 0
+        for key in ("residuals", "stepsizes", "objectives", "solution", "iteration_count", "backtracks", "fused_steps", "comm_launches"):
+            assert np.array_equal(lib[key], py[key]), (r, key)
+            assert np.array_equal(lib[key], runs["library"][0][key]), (r, key)
+    if mode == "forced_backtracking":
+        assert int(runs["library"][0]["backtracks"]) >= 4
+
+
 @pytest.mark.parametrize("fused", ["auto", "on"])
 def test_one_rank_whose_probe_says_no_takes_every_rank_off_the_one_pass_kernel(tmp_path, mock_rccl, fused):
     """the co-residency verdict behind fh_fused_supported is per context and timing-based; ranks that disagreed

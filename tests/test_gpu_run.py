@@ -258,7 +258,7 @@ def test_full_length_histories_of_the_device_loop_against_the_oracle(mode):
         warnings.simplefilter("ignore")
         want = fo.fasta(*P.args7(), stop_rule=fo.residual, **opts)
     k = want.iteration_count
-    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == want.backtracks and 30 < k < 400
+    assert dev.device_steps == dev.iteration_count == k and dev.backtracks == want.backtracks and 15 < k < 400
     for f in ("residuals", "norm_residuals", "stepsizes"):
         np.testing.assert_allclose(getattr(dev, f)[:k], getattr(want, f)[:k], rtol=1e-6, atol=1e-300, err_msg=f)
     np.testing.assert_allclose(dev.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-10)
