@@ -5,11 +5,13 @@ Drop-in for the reference call (fasta/__init__.py:38-53):
     fasta(A, f, gradf, g, proxg, x0, **options)            # 6-positional core form
     fasta(A, At, f, gradf, g, proxg, x0, **options)        # 7-positional form used by the examples
 
-with the reference's options, defaults and `Convergence` result.  Per iteration the host launches ONE kernel --
-the one-pass step (`HipContext.step` / `step_accel`: both directions from a single read of A, or one stencil sweep) --
-wherever the operator shape has one and it pays, otherwise K-fwd (`HipContext.fwd`) and K-adj (`HipContext.adj`), plus
-one more launch per backtrack; it reads back the 16 float64 scalars of the FH_S_* block to take the reference's branch
-decisions (backtracking test :200, restart test :231, Barzilai-Borwein rule :253-270, stop rule :308).
+with the reference's options, defaults and `Convergence` result.  Per iteration ONE kernel is launched -- the one-pass step
+(`fh_step` / `fh_step_accel`: both directions from a single read of A, or one stencil sweep) -- wherever the operator shape has one
+and it pays, otherwise K-fwd and K-adj, plus one more launch per backtrack; the 16 float64 scalars of the FH_S_* block that the launch
+returns drive the reference's branch decisions (backtracking test :200, restart test :231, Barzilai-Borwein rule :253-270, stop rule :308).
+Those decisions are taken, by default, by the LIBRARY's own host-side loop (`HipContext.iterate`, csrc/fh_host_iterate.h: the arithmetic
+of `FBSolver.step` below, bit for bit, without the interpreter between two launches); `driver="python"` keeps them here,
+`driver="device"` moves the whole loop into a persistent launch where a kernel for it exists (csrc/fh_run.h).
 Iterates, gradients and residual vectors never leave HBM unless `record_iterates` / `func` ask.
 
 Which loop runs is decided by the operand TYPES alone (`_recognise`), never by whether a GPU happens to be there:
