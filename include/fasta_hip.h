@@ -196,7 +196,9 @@ int fh_init(fh_ctx* ctx, double* scalars);
  * FH_S_DG2 = ||A^H grad f(A T0) - A^H grad f(A T1)||^2 and FH_S_DX2 = ||T0 - T1||^2 (L = sqrt of their quotient, :110).
  * FH_VEC_T2 / FH_VEC_T3 are scratch afterwards.  A dense float64 least-squares operator with n <= 65536 on a single-device context
  * is read ONCE for the whole set-up (csrc/fh_setup.h: two dot products and two rank-1 updates per row buffer -- x0, and the probes'
- * difference, since grad(T0) - grad(T1) = A^T A (T0 - T1) there); every other operator takes the three passes fh_gradient_at x 2 +
+ * difference, since grad(T0) - grad(T1) = A^T A (T0 - T1) there); ROW BLOCKS (a multi-device context, a rank with a communicator) read
+ * their block once each and sum the two gradients, the loss sums and the timeout words in one exchange -- a rank first settles the decision
+ * with its peers: fh_setup is COLLECTIVE on a context with a communicator; every other operator takes the three passes fh_gradient_at x 2 +
  * fh_init inside the call.  z, f, g0 are bit-identical either way; the norm of the gradient difference agrees to ~1e-15 relative.  */
 int fh_setup(fh_ctx* ctx, double* scalars);
 /* dst = A^H grad f(A src) for n-length device vectors (Lipschitz probes, fasta/__init__.py:106-107) */
@@ -258,8 +260,8 @@ int fh_step_accel(fh_ctx* ctx, double tau, double coef, int restart, double* sca
  * backtracking test with its retries (:195-217), FISTA restart and alpha recursion (:220-238), Barzilai-Borwein step (:253-270),
  * residuals, best iterate (:272-300) and ONE OF THE FOUR BUILT-IN stop rules (fasta/stopping.py:6-51) -- in ONE persistent launch
  * (csrc/fh_run.h), and returns the iterations' histories in one block.  For short launches, where the fixed cost of a launch and the
- * host round trip between two launches dominate (n <= 4096: a workgroup owns whole rows).  Arithmetic and decisions are those of the
- * per-iteration path (fh_step + the host driver), so iteration and backtrack counts are the same and histories agree to rounding.
+ * host round trip between two launches dominate (a workgroup owns whole rows: n <= 6144).  Arithmetic and decisions are those of the
+ * per-iteration path (fh_step + fh_iterate), so iteration and backtrack counts are the same and histories agree to rounding.
  *   opts    the options of fasta() the loop reads; stop_rule: 0 residual, 1 norm_residual, 2 ratio_residual, 3 hybrid_residual
  *   state   in/out, carried from call to call: after fh_init / fh_setup set tau_next = tau0, alpha1 = 1, max_residual = -inf,
  *           best_quality = +inf, iteration = backtracks = 0, f_window[0] = f(x0) (f_window[j % 64] holds f_hist[j]; window <= 64)
