@@ -1133,6 +1133,11 @@ static bool chain_ok(fh_ctx* c) {
   const FusedShape sh = fused_shape(c);
   return sh.ppt && sh.team <= 4 && !sh.xlds && chain_lookup(sh, 0) != nullptr;
 }
+extern "C" int fh_abi_sizes(uint64_t sizes[4]) {
+  if (!sizes) return fail(FH_E_ARG, "null argument");
+  sizes[0] = sizeof(fh_run_opts); sizes[1] = sizeof(fh_run_state); sizes[2] = FH_RUN_HIST; sizes[3] = FH_RUN_WINDOW_MAX;
+  return 0;
+}
 extern "C" int fh_run_supported(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
   *yes = ((run_entry(c) || chain_ok(c)) && co_resident(c)) ? 1 : 0;

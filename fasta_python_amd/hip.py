@@ -92,6 +92,7 @@ SIGNATURES = {
     "fh_fwd": (_i32, [_ctx, _dbl, _pd]),
     "fh_adj": (_i32, [_ctx, _dbl, _i32, _dbl, _pd]),
     "fh_commit": (_i32, [_ctx, _i32]),
+    "fh_abi_sizes": (_i32, [C.POINTER(_u64)]),
     "fh_run_supported": (_i32, [_ctx, C.POINTER(_i32)]),
     "fh_run": (_i32, [_ctx, _i32, C.POINTER(RunOpts), C.POINTER(RunState), _pd, C.POINTER(_i32)]),
     "fh_iterate": (_i32, [_ctx, _i32, C.POINTER(RunOpts), C.POINTER(RunState), _pd, C.POINTER(_i32)]),
@@ -155,6 +156,13 @@ def load_library(path=None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    # the structs that cross the boundary by pointer: this binding's layouts must be the library's (a stale .so next to a newer hip.py, or the
+    # other way round, would otherwise read and write past each other's fields)
+    sizes = (_u64 * 4)()
+    _check(lib, lib.fh_abi_sizes(sizes))
+    if tuple(sizes) != (C.sizeof(RunOpts), C.sizeof(RunState), RUN_HIST, RUN_WINDOW_MAX):
+        raise HipError(f"{path}: fh_run_opts / fh_run_state / history layout {tuple(sizes)} does not match this binding's "
+                       f"{(C.sizeof(RunOpts), C.sizeof(RunState), RUN_HIST, RUN_WINDOW_MAX)} -- rebuild the library (python __graft_entry__.py)")
     _lib = lib
     return lib
 

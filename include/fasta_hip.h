@@ -299,6 +299,9 @@ typedef struct fh_run_state {
   int64_t onepass_off_until;         /* -1, or the iteration from which the one-pass kernel is tried again after a hand-off timeout    */
   uint64_t onepass_launches, pair_launches, onepass_timeouts;   /* totals: one-pass launches that delivered, pairs, hand-off timeouts  */
 } fh_run_state;
+/* sizeof(fh_run_opts), sizeof(fh_run_state), FH_RUN_HIST, FH_RUN_WINDOW_MAX as THIS build of the library sees them: a binding checks its own
+ * struct layouts against them before the first call (fasta_python_amd/hip.py:load_library does).  No device needed.                           */
+int fh_abi_sizes(uint64_t sizes[4]);
 int fh_run_supported(fh_ctx* ctx, int* yes);
 /* After a grid-barrier timeout of the persistent launch (workgroups not co-resident) fh_run returns FH_E_TIMEOUT with state->stopped = 3:
  * the context and `state` are those of the last COMPLETED iteration (state->tau_next = the step the interrupted iteration started with),

@@ -165,6 +165,109 @@ class FakeContext:
         self.calls["adj"] -= 1
         return a
 
+    # ---- the library's host-side loop (csrc/fh_host_iterate.h: fh_iterate), restated on this stand-in -----------------------------------
+    def iterate(self, max_steps, o, st):
+        """NumPy twin of fh_iterate: the same launches by the same policy, the expressions of fasta_python_amd/solver.py:FBSolver.step for the
+        decisions, the same history records and state updates -- so that the CPU tier can drive `FBSolver._library_call` (history slices,
+        state carried from call to call, verbose lines, launch counters) without a GPU."""
+        import math
+        sq = lambda v: np.float64(math.sqrt(v))
+        fval = (lambda s_: np.float64(s_)) if self.loss == "logistic" else (lambda s_: .5 * sq(s_) ** 2)
+        gval = {hip.PROX_SHRINK: lambda gs, gm: self.mu * gs, hip.PROX_LINF: lambda gs, gm: self.mu * gm}.get(self.prox_kind, lambda gs, gm: 0)
+        hist = np.zeros((int(max_steps), hip.RUN_HIST))
+        always = o.launch_mode == hip.LAUNCH_ONEPASS_ALWAYS
+        if st.onepass_backoff <= 0:
+            st.onepass_backoff = 64
+        st.stopped = 0
+
+        def forward(tau, one_pass, alpha1):
+            if o.launch_mode == hip.LAUNCH_PAIR and one_pass:
+                st.pair_launches += 1
+                return self.fwd_adj(tau), True
+            fused_on = o.launch_mode in (hip.LAUNCH_ONEPASS_ALWAYS, hip.LAUNCH_ONEPASS_SPECULATIVE) and st.onepass_off_until < 0
+            if fused_on and one_pass:
+                try:
+                    if o.accelerate:
+                        a1 = (1 + np.sqrt(1 + 4 * alpha1 ** 2)) / 2
+                        s_ = self.step_accel(tau, (alpha1 - 1) / a1, bool(o.restart))
+                    else:
+                        s_ = self.step(tau)
+                    st.onepass_launches += 1
+                    return s_, True
+                except hip.HipTimeout:
+                    st.onepass_off_until = int(st.iteration) + st.onepass_backoff
+                    st.onepass_backoff *= 2
+                    st.onepass_timeouts += 1
+            return self.fwd(tau), False
+
+        done = 0
+        for step in range(int(max_steps)):
+            i = int(st.iteration)
+            tau = np.float64(st.tau_next)
+            if st.onepass_off_until >= 0 and i >= st.onepass_off_until:
+                st.onepass_off_until = -1
+            speculate = always or st.spec_cooldown == 0
+            s, have_adj = forward(tau, speculate, np.float64(st.alpha1))
+            if not speculate:
+                st.spec_cooldown -= 1
+            f1 = fval(s[hip.S_FSQ])
+            bt = 0
+            if o.backtrack:
+                lo = max(i - o.window + 1, 0)
+                M = np.array([st.f_window[j % hip.RUN_WINDOW_MAX] for j in range(lo, i + 1)]).max()
+                while f1 - (M + s[hip.S_DXG0] + sq(s[hip.S_DX2]) ** 2 / (2 * tau)) > 1E-12 and bt < o.max_backtracks:
+                    tau = tau * o.stepsize_shrink
+                    s, have_adj = forward(tau, always, np.float64(st.alpha1))
+                    f1 = fval(s[hip.S_FSQ])
+                    bt += 1
+                if bt:
+                    st.spec_cooldown = 8
+            alpha0, coef, alpha1, restarted = 0.0, 0.0, np.float64(st.alpha1), False
+            if o.accelerate:
+                alpha0 = alpha1
+                if o.restart and s[hip.S_RDOT] > 1E-30:
+                    alpha0, restarted = 1.0, True
+                alpha1 = (1 + np.sqrt(1 + 4 * alpha0 ** 2)) / 2
+                coef = (alpha0 - 1) / alpha1
+            a = s if have_adj else self.adj(tau, bool(o.accelerate), coef)
+            if o.accelerate:
+                f1 = fval(a[hip.S_FSQ_ADJ])
+                xh2, gsum, gmax = a[hip.S_XH2_ADJ], a[hip.S_GSUM_ADJ], a[hip.S_GMAX_ADJ]
+            else:
+                xh2, gsum, gmax = s[hip.S_XH2], s[hip.S_GSUM], s[hip.S_GMAX]
+            tau_next = tau
+            dx_norm = sq(s[hip.S_DX2])
+            if o.adaptive:
+                dot = a[hip.S_DXDG]
+                tau_s = dx_norm ** 2 / dot
+                tau_m = max(dot / sq(a[hip.S_DG2]) ** 2, 0)
+                tau_next = tau_m if 2 * tau_m > tau_s else tau_s - .5 * tau_m
+                if tau_next <= 0 or np.isinf(tau_next) or np.isnan(tau_next):
+                    tau_next = tau * 1.5
+            resid = dx_norm / tau
+            norm_resid = resid / (max(sq(s[hip.S_G02]), sq(xh2) / tau) + 1E-12)
+            st.max_residual = max(st.max_residual, resid)
+            objective, quality = 0.0, resid
+            if o.evaluate_objective:
+                objective = f1 + gval(gsum, gmax)
+                quality = objective
+            better = bool(quality < st.best_quality)
+            if better:
+                st.best_quality = quality
+            self.commit(save_best=better)
+            ratio, normed = resid / st.max_residual < o.tolerance, norm_resid < o.tolerance
+            stop = [resid < o.tolerance, normed, ratio, ratio or normed][o.stop_rule]
+            hist[step] = (resid, norm_resid, tau, f1, objective, bt, alpha0, (1.0 if better else 0.0) + (2.0 if restarted else 0.0))
+            st.f_window[(i + 1) % hip.RUN_WINDOW_MAX] = f1
+            st.tau_next, st.alpha1 = tau_next, alpha1
+            st.backtracks += bt
+            st.iteration = i + 1
+            done = step + 1
+            if stop:
+                st.stopped = 1
+                break
+        return hist[:done]
+
     def commit(self, save_best=False):
         self.xacc, self.z_acc = self.xp, self.z1          # FISTA history (pre-extrapolation values)
         self.x0, self.g0 = self.x1, self.g1

@@ -35,6 +35,30 @@ def test_enums_match_header():
         assert m and int(m.group(1)) == value, cname
 
 
+def test_struct_layouts_and_constants_of_the_loop_entry_points_match_the_library():
+    """fh_run_opts / fh_run_state cross the boundary by pointer: the ctypes mirrors must have the library's sizes (fh_abi_sizes; load_library refuses
+    a mismatch), the field order of the header, and the launch-mode / status / tuning constants their header values."""
+    import ctypes as C
+    lib = hip.load_library()
+    sizes = (C.c_uint64 * 4)()
+    assert lib.fh_abi_sizes(sizes) == 0
+    assert tuple(sizes) == (C.sizeof(hip.RunOpts), C.sizeof(hip.RunState), hip.RUN_HIST, hip.RUN_WINDOW_MAX)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fasta_hip.h")).read(), flags=re.S)
+    for struct, mirror in (("fh_run_opts", hip.RunOpts), ("fh_run_state", hip.RunState)):
+        body = re.search(r"typedef struct " + struct + r" \{(.*?)\} " + struct + ";", text, flags=re.S).group(1)
+        names = [n.split("[")[0] for decl in body.split(";") for n in re.sub(r"^\s*(uint64_t|int64_t|double|int)\s+", "", decl.strip()).replace(" ", "").split(",") if decl.strip()]
+        assert names == [f[0] for f in mirror._fields_], struct
+    for cname, value in (("FH_LAUNCH_SEPARATE", hip.LAUNCH_SEPARATE), ("FH_LAUNCH_ONEPASS_ALWAYS", hip.LAUNCH_ONEPASS_ALWAYS),
+                         ("FH_LAUNCH_ONEPASS_SPECULATIVE", hip.LAUNCH_ONEPASS_SPECULATIVE), ("FH_LAUNCH_PAIR", hip.LAUNCH_PAIR),
+                         ("FH_TUNE_RUN_MAX_N", hip.TUNE_RUN_MAX_N), ("FH_TUNE_SEQ_POLL", hip.TUNE_SEQ_POLL), ("FH_TUNE_RUN_CHAIN", hip.TUNE_RUN_CHAIN),
+                         ("FH_TUNE_FUSED_CUS", hip.TUNE_FUSED_CUS)):
+        m = re.search(cname + r"\s*=\s*(\d+)", text)
+        assert m and int(m.group(1)) == value, cname
+    for cname, value in (("FH_E_TIMEOUT", hip.E_TIMEOUT), ("FH_E_STATE", hip.E_STATE)):
+        m = re.search(r"#define\s+" + cname + r"\s+(\d+)", text)
+        assert m and int(m.group(1)) == value, cname
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(hip.HipError):
         hip.load_library(str(tmp_path / "nope.so"))

@@ -15,7 +15,7 @@ from tests.gpu_util import TAGS
 CASES = [n for n in H.golden_cases() if not n.startswith("c1_")]
 
 
-def _run(name, fused, dense_kind=1):
+def _run(name, fused, dense_kind=1, **extra):
     meta, z = H.load_case(name)
     data = H.case_data(meta, z)
     kind = meta["kind"]
@@ -33,7 +33,8 @@ def _run(name, fused, dense_kind=1):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         # kind 3 (one-pass kernel available but not recommended at this size) is only used when forced
-        c = fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=False, fused=True if (fused and dense_kind == 3 and kind != "tv") else "auto", **o)
+        c = fa.fasta(A, A.H, loss.f, loss.gradf, g, proxg, x0, verbose=extra.pop("verbose", False),
+                     fused=True if (fused and dense_kind == 3 and kind != "tv") else "auto", **dict(o, **extra))
     return meta, z, c, A.ctx
 
 
@@ -71,6 +72,40 @@ def test_driver_reproduces_reference_run(name, fused):
             assert ctx.calls["fwd"] > 0 and ctx.calls["adj"] > 0   # retries and the cool-down iterations go the plain way
     else:
         assert ctx.calls["pair"] == 0
+
+
+@pytest.mark.parametrize("fused", [False, True, 3])
+@pytest.mark.parametrize("name", CASES)
+def test_library_loop_plumbing_equals_the_python_driver(name, fused):
+    """Round 6: by default the decisions between two launches are taken by the library's host-side loop (fh_iterate) in calls of several
+    iterations; `FBSolver._library_call` slices its history records into the reference's arrays and carries solver state and launch policy
+    from call to call.  With the NumPy twin of fh_iterate on the stand-in context (tests/fake_ctx.py) that plumbing runs on the CPU tier:
+    every fixture, calls of 7 iterations and time-sized calls, against the Python driver -- EQUAL histories, counts, solutions and launch
+    counters (the same launches produced the same numbers); options that need Python between iterations keep `step()`."""
+    meta, z, py, ctx_py = _run(name, bool(fused), dense_kind=3 if fused == 3 else 1, driver="python")
+    needs_python = bool(meta["options"].get("record_iterates") or meta["options"].get("func"))
+    for kw in (dict(driver="library", device_iters=7), {}):
+        _, _, lib, ctx = _run(name, bool(fused), dense_kind=3 if fused == 3 else 1, **kw)
+        assert lib.library_steps == (0 if needs_python else lib.iteration_count) and py.library_steps == 0
+        assert lib.iteration_count == py.iteration_count and lib.backtracks == py.backtracks
+        for f in ("residuals", "norm_residuals", "stepsizes", "objectives", "function_hist", "iterates", "solution"):
+            a, b = getattr(lib, f), getattr(py, f)
+            assert (a is None) == (b is None), f
+            if a is not None:
+                assert np.array_equal(a, b, equal_nan=True), f
+        assert ctx.calls == ctx_py.calls
+
+
+@pytest.mark.parametrize("name", ["sparse_ls_64x128_accelerated", "sparse_ls_unnormalised_backtracks", "tv_32x32_adaptive"])
+def test_verbose_lines_from_history_records_are_the_reference_text(name, capsys):
+    """verbose=True (the reference's default): header, one line per iteration, "Restarted acceleration." -- printed per iteration by the Python
+    driver and per call, from the history records, by the library loop: the same text."""
+    _run(name, True, driver="python", verbose=True)
+    want = capsys.readouterr().out
+    _run(name, True, driver="library", device_iters=5, verbose=True)
+    got = capsys.readouterr().out
+    assert want.startswith("Initializing FASTA...") and want.count("\n[") > 5
+    assert got == want
 
 
 def test_speculation_backs_off_after_a_backtrack():
