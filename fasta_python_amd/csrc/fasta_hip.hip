@@ -709,6 +709,7 @@ static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
   return 0;
 }
 
+static __global__ void k_set_pair(double* w, double a, double b) { w[0] = a; w[1] = b; }
 // the one-read set-up kernel of this context's shape, or nullptr (the three passes then): dense float64 least squares, n <= 65536, large enough to pay
 static const SetupEntry* setup_entry(fh_ctx* c) {
   if (c->op != OP_DENSE || c->f32 || c->loss_kind != LOSS_LSQ || !fused_pays(c)) return nullptr;
@@ -734,11 +735,19 @@ static int setup_row_blocks(fh_ctx* c, double* scalars, bool* done) {
   *done = false;
   const int ns = nshards(c);
   bool all = true;
-  for (int k = 0; k < ns; ++k) { fh_ctx* s = shard_of(c, k); if (!setup_entry(s) || (c->shards.empty() ? false : !co_resident(s))) all = false; }
-  if (c->shards.empty()) {              // a rank: the verdict of ALL ranks (1 = the one-pass kernel is available and recommended everywhere)
-    int kind = 0;
-    FH_TRY(fh_fused_agree(c, &kind));
-    if (kind != 1) all = false;
+  for (int k = 0; k < ns; ++k) { fh_ctx* s = shard_of(c, k); if (!setup_entry(s) || !co_resident(s)) all = false; }
+  if (c->shards.empty()) {
+    // a rank: EVERY rank must take the same way (the two ways issue different collectives), and a rank's own verdict depends on its local rows
+    // and its own co-residency probe: the "no" verdicts are summed over the communicator -- whatever this rank found, it enters the exchange
+    double* w = c->dscal + FH_NSCALARS + 8;              // scratch behind the scalar block (as fh_fused_agree)
+    double* back = c->hscal + FH_NSCALARS + 8;
+    FH_TRY(use_device(c));
+    k_set_pair<<<dim3(1), dim3(1), 0, c->stream>>>(w, all ? 0.0 : 1.0, 0.0);
+    HIP_TRY(hipGetLastError());
+    FH_TRY(sum_over_shards(c, [w](fh_ctx*) { return w; }, 2));
+    HIP_TRY(hipMemcpyAsync(back, w, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    all = back[0] == 0.0;
   }
   if (!all) return 0;
   for (int k = 0; k < ns; ++k) {
@@ -948,7 +957,6 @@ extern "C" int fh_fused_supported(fh_ctx* c, int* yes) {
 // hang; the failure is then returned on that rank.  Never cached: a cache keyed on local state could make one rank skip an
 // exchange its peers enter.  Without a communicator (plain context, or a multi-device context, whose shards are combined in one
 // process) it is the local query.
-static __global__ void k_set_pair(double* w, double a, double b) { w[0] = a; w[1] = b; }
 extern "C" int fh_fused_agree(fh_ctx* c, int* yes) {
   if (!c || !yes) return fail(FH_E_ARG, "null argument");
   int kind = 0;
