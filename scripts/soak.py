@@ -159,8 +159,59 @@ def side_by_side(cus, iters):
           f"no timeout; bitwise identical to the solve that ran alone: {same}", flush=True)
     assert same
 
+def seq_wait(name, make_op, loss_reg, iters, extra=None):
+    """round 6: a step waits for its scalar block by the sequence number the launch writes behind it (FH_TUNE_SEQ_POLL) and the decisions are taken
+    by the library's host-side loop: tens of thousands of iterations, three ways -- library loop + sequence number (default), library loop +
+    hipStreamSynchronize, Python driver + sequence number -- must give EQUAL histories: one stale entry of one scalar block would change a decision."""
+    runs = {}
+    for tag, poll, driver in (("library, sequence number", 1, "library"), ("library, stream synchronisation", 0, "library"), ("python, sequence number", 1, "python")):
+        A = make_op()
+        try:
+            A.ctx.set_tuning(hip.TUNE_SEQ_POLL, poll)
+            loss, reg, x0 = loss_reg(A)
+            np.random.seed(3)
+            solver = fa.FBSolver(A, loss, reg, x0, verbose=False, max_iters=iters, tolerance=0.0, driver=driver, **(extra or {}))
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                solver.setup()
+                t0 = time.perf_counter()
+                c = solver.run()
+                dt = time.perf_counter() - t0
+            runs[tag] = (c.residuals.copy(), c.stepsizes.copy(), c.solution.copy(), c.backtracks)
+            print(f"{name} [{tag}]: {c.iteration_count} iterations, {c.backtracks} backtracks, {c.iteration_count / dt:9.1f} it/s", flush=True)
+        finally:
+            A.close()
+    ref = runs["library, sequence number"]
+    same = all(all(np.array_equal(a, b_, equal_nan=True) for a, b_ in zip(r[:3], ref[:3])) and r[3] == ref[3] for r in runs.values())
+    print(f"{name}: the three ways bitwise identical: {same}", flush=True)
+    assert same
+
+def lasso_op(m, n):
+    return lambda: fa.DenseMatrixMap.synthetic(m, n, 0, synthetic.lasso_scale(m, n))
+
+def lasso_terms(A):
+    n = A.Vshape[0]
+    b = synthetic.lasso_observation(A, synthetic.sparse_signal(n, 1), 2, 0.01)
+    return fa.LeastSquares(b), fa.Shrink(0.02), np.zeros(n)
+
+def tv_small_op(side):
+    return lambda: fa.GradDivMap((side, side))
+
+def tv_small_terms(A):
+    from fasta_python_amd.examples.tv_denoising import checkerboard
+    side = A.image_shape[0]
+    np.random.seed(7)
+    M = checkerboard(side, side, max(1, side // 32)) + 0.1 * np.random.standard_normal((side, side))
+    return fa.LeastSquares(M / 0.1), fa.TVDualBall(), np.zeros(M.shape + (2,))
+
 # (tvring / tvslots: the experimental library only -- FASTA_HIP_LIB=fasta_python_amd/libfasta_hip_experimental.so python scripts/soak.py tvring,tvslots)
-which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["dense", "f32", "l1ball", "linf", "devloop", "setup", "tv", "tvacc", "blocks8", "config5", "pair128"]
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["seq", "dense", "f32", "l1ball", "linf", "devloop", "setup", "tv", "tvacc", "blocks8", "config5", "pair128"]
+if "seq" in which:
+    seq_wait("LASSO 8192^2", lasso_op(8192, 8192), lasso_terms, 30000)
+    seq_wait("LASSO 2048x3000, FISTA", lasso_op(2048, 3000), lasso_terms, 30000, dict(adaptive=False, accelerate=True))
+    seq_wait("LASSO 600x1000, two launches per iteration", lasso_op(600, 1000), lasso_terms, 30000, dict(fused=False))
+    seq_wait("TV 512^2 adaptive", tv_small_op(512), tv_small_terms, 30000)
+    seq_wait("TV 512^2 FISTA", tv_small_op(512), tv_small_terms, 30000, dict(adaptive=False, accelerate=True))
 if "devloop" in which:
     device_loop(4096, 4096, 20000, 64)
     device_loop(512, 1024, 50000, 512)
