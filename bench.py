@@ -989,13 +989,16 @@ def main(argv=None):
         else:
             # opt-in float32-storage mode on the same synthetic matrix (rounded to float32): a SEPARATE line, never the headline
             A32 = shard(m_total, "f32")
+            nat32 = None
             try:
                 r = run_dense(args, grp, A32, m_total, n, "lasso", fused, args.steps, args.warmup)
+                nat32 = natural_runs(A32, n, m_total)["lasso"]        # (its set-up is one read of the float32 matrix since round 6)
             finally:
                 A32.close()
                 settle_after_free(m_total * n * 4 / 2 ** 30)
             s32 = sub_result(r, f"LASSO {m_total}x{n}, A stored float32 (opt-in; vectors, accumulation and scalars float64)")
             s32["dtype"] = "f32-storage"
+            s32["natural_run"] = nat32
             s32["tolerance"] = ("iterates equal the reference's run on A.astype(float32) to the float64 path's tolerances; against the "
                                 "float64-matrix run they differ by the rounding of A (<= 3e-7 relative away from the chaotic regime)")
             extra["lasso_f32_storage"] = s32

@@ -83,21 +83,27 @@ static const ChainEntry kChainTable[] = {
 // the set-up kernel's variants: the same scheme, fh_setup_instances.inc / fh_setup_part.hip
 #ifndef FH_SINGLE_TU
 #define FH_SETUP_DECLARE(P, PI, T, NT, NR) extern template __global__ void k_setup_dense<P, PI, T, NT, NR>(const SetupP);
+#define FH_SETUP_DECLARE32(P, PI, T, NT, NR) extern template __global__ void k_setup_dense<P, PI, T, NT, NR, 1>(const SetupP);
 #define SETUP_INST_0 FH_SETUP_DECLARE
 #define SETUP_INST_1 FH_SETUP_DECLARE
+#define SETUP_INST_2 FH_SETUP_DECLARE32
 #include "fh_setup_instances.inc"
 #undef SETUP_INST_0
 #undef SETUP_INST_1
+#undef SETUP_INST_2
 #endif
-struct SetupEntry { int ppt, pipe, team, threads, nr; void (*kernel)(const SetupP); };
-#define FH_SETUP_ROW(P, PI, T, NT, NR) {P, PI, T, NT, NR, k_setup_dense<P, PI, T, NT, NR>},
+struct SetupEntry { int ppt, pipe, team, threads, nr, f32; void (*kernel)(const SetupP); };
+#define FH_SETUP_ROW(P, PI, T, NT, NR) {P, PI, T, NT, NR, 0, k_setup_dense<P, PI, T, NT, NR>},
+#define FH_SETUP_ROW32(P, PI, T, NT, NR) {P, PI, T, NT, NR, 1, k_setup_dense<P, PI, T, NT, NR, 1>},
 #define SETUP_INST_0 FH_SETUP_ROW
 #define SETUP_INST_1 FH_SETUP_ROW
+#define SETUP_INST_2 FH_SETUP_ROW32
 static const SetupEntry kSetupTable[] = {
 #include "fh_setup_instances.inc"
 };
 #undef SETUP_INST_0
 #undef SETUP_INST_1
+#undef SETUP_INST_2
 
 #include "fh_host_ctx.h"
 #include "fh_host_launch.h"
@@ -666,10 +672,12 @@ static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
   if (!sharded && (row_sharded(c) || !c->shards.empty())) return 0;
   const SetupEntry* e = setup_entry(c);
   if (!e || !co_resident(c)) return 0;
-  const FusedShape sh = fused_shape(c);
+  struct { int team; } sh = {e->team};               // (the set-up kernel's own team size: float32 storage does not follow the step kernel's shape)
   SetupP p;
   p.A = c->A; p.n = (uint32_t)c->n; p.m = (uint32_t)c->m; p.mp = (uint32_t)c->mp;
-  p.ld2 = (uint32_t)(round_up(c->n, 16) / 2); p.ldp = (uint32_t)(c->ld / 2); p.nv2 = p.ld2;
+  p.ld2 = (uint32_t)(c->f32 ? round_up(c->n, 32) / 4 : round_up(c->n, 16) / 2);
+  p.ldp = (uint32_t)(c->ld / (c->f32 ? 4 : 2));
+  p.nv2 = p.ld2 * (c->f32 ? 2u : 1u);
   p.nteams = (uint32_t)(fused_ncu(c) / sh.team);
   if (c->fused_min_rows > 0) {
     const uint64_t want = std::max<uint64_t>(8, round_up((c->mp + c->fused_min_rows - 1) / c->fused_min_rows, 8));
@@ -712,13 +720,29 @@ static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
 static __global__ void k_set_pair(double* w, double a, double b) { w[0] = a; w[1] = b; }
 // the one-read set-up kernel of this context's shape, or nullptr (the three passes then): dense float64 least squares, n <= 65536, large enough to pay
 static const SetupEntry* setup_entry(fh_ctx* c) {
-  if (c->op != OP_DENSE || c->f32 || c->loss_kind != LOSS_LSQ || !fused_pays(c)) return nullptr;
+  if (c->op != OP_DENSE || c->loss_kind != LOSS_LSQ || !fused_pays(c)) return nullptr;
+  if (c->f32) {
+    // float32 storage (round 6): a member covers 256 x (at most 4) four-column pieces -- two right-hand sides cost 16 accumulator registers per
+    // piece, five pieces spill into the row loop -- so the team is as large as the row needs (n <= 65536: up to 16 members), ONE workgroup per CU;
+    // its own rows of the table (fh_setup_instances.inc, group 2), not the step kernel's shape
+    if (c->ld % 4 || fused_ncu(c) < 1) return nullptr;
+    const uint64_t pieces = round_up(c->n, 32) / 4;
+    for (int team = 1; team <= 16; team *= 2) {
+      if (pieces > (uint64_t)team * FH_WG * 4) continue;
+      if (fused_ncu(c) % team) return nullptr;
+      int mpp = (int)((pieces + (uint64_t)team * FH_WG - 1) / ((uint64_t)team * FH_WG));
+      if (mpp == 3 || team > 1) mpp = 4;
+      for (const SetupEntry& k : kSetupTable) if (k.f32 == 1 && k.ppt == mpp && k.team == team) return &k;
+      return nullptr;
+    }
+    return nullptr;
+  }
   const FusedShape sh = fused_shape(c);
   if (!sh.ppt || sh.xlds) return nullptr;
   // full 8-piece shapes of 8 / 16 members: 512-thread workgroups (fh_setup_instances.inc); FH_TUNE_FUSED_VARIANT bit 16 keeps the 256-thread form (A/B)
   const int want_threads = (sh.ppt == 8 && sh.team >= 8 && sh.team <= 16 && !(c->fused_variant & 16)) ? 512 : 256;
-  for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe) && k.threads == want_threads) return &k;
-  if (want_threads == 512) for (const SetupEntry& k : kSetupTable) if (k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) return &k;
+  for (const SetupEntry& k : kSetupTable) if (!k.f32 && k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe) && k.threads == want_threads) return &k;
+  if (want_threads == 512) for (const SetupEntry& k : kSetupTable) if (!k.f32 && k.ppt == sh.ppt && k.team == sh.team && k.pipe == (sh.team == 1 ? 1 : sh.pipe)) return &k;
   return nullptr;
 }
 

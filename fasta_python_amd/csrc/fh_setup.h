@@ -17,8 +17,8 @@
 //     agrees with the three-pass value to ~1e-15 relative -- tests/test_gpu_setup.py;
 //   * the finaliser also forms ||A^T A d||^2 and (team 0's prologue) ||x1 - x2||^2: the two norms of :110 come back with the scalar
 //     block, no further launch.
-// Shapes: float64 storage, PPT <= 8 (n <= 65536): NR x PPT x 4 KiB of LDS for the x slices, NR x PPT x 4 registers for the gradient
-// slices.  Wider rows, float32 storage and the logistic loss keep the three-pass set-up (fh_setup falls back by itself).  Row blocks
+// Shapes: PPT <= 8 pieces per lane (n <= 65536 in float64 storage, <= 131072 in float32 storage): NR x PPT x 4 (8) KiB of LDS for the x slices,
+// NR x PPT x 4 (8) registers for the gradient slices.  Wider rows and the logistic loss keep the three-pass set-up (fh_setup falls back by itself).  Row blocks
 // (round 6: a multi-device context, or a rank of a row-sharded run) launch it per block -- it is linear in the rows like least squares
 // itself -- and sum A_k^T A_k d, the gradients and the loss sums in ONE exchange (csrc/fasta_hip.hip:setup_row_blocks).  The slots are filled with the sentinel by the host before the launch (one launch per solve: no re-arming).
 #pragma once
@@ -89,13 +89,18 @@ __device__ __forceinline__ void fs_block_reduce(double (&v)[K], double* scr) {
 //         one exchange and one rank-1 update fewer per row, 64 instead of 96 accumulator registers.  ||A^T A d|| equals
 //         ||grad(x1) - grad(x2)|| up to rounding (no cancellation: the probes are independent), so L = that / ||d|| agrees with the
 //         three-pass value to ~1e-15 relative; z, f and g0 do not depend on the probes at all.
-template <int MPP, int PIPE, int TEAM, int NT, int NR>
+// F32 = 1 (round 6): float32 storage of A -- a piece is four columns (fh_device.h: PieceOf), so a lane's x entries and gradient accumulators are
+// XD = 2 double pairs per piece: twice the LDS (NR x PPT x 8 KiB) and twice the accumulator registers (NR x PPT x 8) of the float64 kernel;
+// 256 threads, one wave per SIMD (512 registers), NR = 2.
+template <int MPP, int PIPE, int TEAM, int NT, int NR, int F32 = 0>
 __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
-  typedef d2 PT;
+  typedef typename PieceOf<F32>::type PT;
+  constexpr int XD = xd2<F32>();
   static_assert(NR == 2 || NR == 3, "two or three right-hand sides");
+  static_assert(!F32 || (NR == 2 && NT == 256), "float32 storage: two right-hand sides, 256 threads");
   constexpr int NW = NT / 64;
   constexpr int PPT = (MPP * FH_WG + NT - 1) / NT;                      // pieces per lane
-  __shared__ __attribute__((aligned(16))) d2 s_x[NR * PPT * NT];
+  __shared__ __attribute__((aligned(16))) d2 s_x[NR * PPT * XD * NT];
   __shared__ __attribute__((aligned(16))) d2 s_fin[FH_WG];
   __shared__ __attribute__((aligned(16))) double s_part[NR][NW];
   __shared__ __attribute__((aligned(16))) double s_part2[2][NR][NW];     // TEAM == 1: double-buffered by trip parity
@@ -123,39 +128,45 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
 #pragma unroll
     for (int k = 0; k < PPT; ++k) buf[k] = load_stream<1>(src + pc[k]);
   };
-  constexpr int NB = NT == 512 ? 4 : (PPT >= 7 ? (NR == 2 && PIPE >= 2 ? 5 : 4) : (PPT >= 5 ? 5 : 6));      // row buffers: what fits next to the gradient slices (512 threads: 256 registers per lane)
+  constexpr int NB = F32 ? (PPT >= 4 ? 4 : 6)       // float32 storage: a piece's accumulators are twice as wide -- four row buffers next to 4 pieces x 2 right-hand sides
+                         : (NT == 512 ? 4 : (PPT >= 7 ? (NR == 2 && PIPE >= 2 ? 5 : 4) : (PPT >= 5 ? 5 : 6)));      // row buffers: what fits next to the gradient slices (512 threads: 256 registers per lane)
   PT B[NB][PPT];
 
   // ---------------- n-side: the three x slices into LDS (each lane reads back only its own entries); ||x1 - x2||^2 by team 0
   double dx2 = 0.0;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const uint32_t c = c0 + k * NT;
     const bool ok = piece_ok(k);
-    d2 xin[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      xin[j] = reinterpret_cast<const d2*>(p.x[j])[pc[k]];
+    for (int h = 0; h < XD; ++h) {
+      const uint32_t c = (c0 + k * NT) * XD + h;                    // double-pair index into the n-side vectors (validity); pc[k] * XD + h: clamped (loads)
+      d2 xin[3];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) if (!(ok && (2u * c + e) < p.n)) xin[j][e] = 0.0;     // lanes past the member's / the row's last column carry 0
+      for (int j = 0; j < 3; ++j) {
+        xin[j] = reinterpret_cast<const d2*>(p.x[j])[pc[k] * XD + h];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) if (!(ok && (2u * c + e) < p.n)) xin[j][e] = 0.0;     // lanes past the member's / the row's last column carry 0
+      }
+      d2 dif;
+      dif.x = sub_nofma(xin[0].x, xin[1].x); dif.y = sub_nofma(xin[0].y, xin[1].y);
+      if (NR == 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s_x[((j * PPT + k) * XD + h) * NT + tid] = xin[j];
+      } else {
+        s_x[((0 * PPT + k) * XD + h) * NT + tid] = dif;
+        s_x[((1 * PPT + k) * XD + h) * NT + tid] = xin[2];
+      }
+      if (team == 0) { dx2 = fma(dif.x, dif.x, dx2); dx2 = fma(dif.y, dif.y, dx2); }
     }
-    d2 dif;
-    dif.x = sub_nofma(xin[0].x, xin[1].x); dif.y = sub_nofma(xin[0].y, xin[1].y);
-    if (NR == 3) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) s_x[(j * PPT + k) * NT + tid] = xin[j];
-    } else {
-      s_x[(0 * PPT + k) * NT + tid] = dif;
-      s_x[(1 * PPT + k) * NT + tid] = xin[2];
-    }
-    if (team == 0) { dx2 = fma(dif.x, dif.x, dx2); dx2 = fma(dif.y, dif.y, dx2); }
   }
 
-  d2 ga[NR][PPT];
+  d2 ga[NR][PPT][XD];
 #pragma unroll
   for (int j = 0; j < NR; ++j)
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) ga[j][k] = (d2){0.0, 0.0};
+    for (int k = 0; k < PPT; ++k)
+#pragma unroll
+      for (int h = 0; h < XD; ++h) ga[j][k][h] = (d2){0.0, 0.0};
   double fs = 0.0;
   bool dead = false;
   // LEAST SQUARES ONLY (the host takes the three passes for the logistic loss: its exp / log constants do not fit next to three
@@ -218,14 +229,16 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
   // into ONE register quad and waits for each of the 3 x PPT LDS round trips in turn -- the dot products are then LDS-latency bound)
   auto dot_row = [&](const PT (&buf)[PPT], double (&d)[NR]) {
     double part[NR] = {};
-    d2 xa[NR], xb[NR];
-    auto fetch = [&](d2 (&xv)[NR], int k) {
+    d2 xa[NR][XD], xb[NR][XD];
+    auto fetch = [&](d2 (&xv)[NR][XD], int k) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) xv[j] = s_x[(j * PPT + k) * NT + tid];
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int h = 0; h < XD; ++h) xv[j][h] = s_x[((j * PPT + k) * XD + h) * NT + tid];
     };
-    auto mul = [&](const PT& a, const d2 (&xv)[NR]) {
+    auto mul = [&](const PT& a, const d2 (&xv)[NR][XD]) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) { part[j] = fma(a.x, xv[j].x, part[j]); part[j] = fma(a.y, xv[j].y, part[j]); }
+      for (int j = 0; j < NR; ++j) part[j] = piece_dot(a, xv[j], part[j]);      // (float64: fma(a.x, x.x, .), fma(a.y, x.y, .) -- the order of k_fused_dense)
     };
     fetch(xa, 0);
 #pragma unroll
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) { ga[j][k].x = fma(buf[k].x, rv[j], ga[j][k].x); ga[j][k].y = fma(buf[k].y, rv[j], ga[j][k].y); }
+      for (int k = 0; k < PPT; ++k) piece_axpy(buf[k], rv[j], ga[j][k]);
   };
   const auto* bq = (const __attribute__((address_space(4))) double*)(uintptr_t)p.b;
 
@@ -374,8 +387,11 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
   for (int j = 0; j < NR; ++j)
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
-      if (piece_ok(k))
-        store_partial16(reinterpret_cast<d2*>(p.gpart) + ((uint64_t)team * NR + j) * p.nv2, c0 + k * NT, ga[j][k]);
+      if (piece_ok(k)) {
+#pragma unroll
+        for (int h = 0; h < XD; ++h)
+          store_partial16(reinterpret_cast<d2*>(p.gpart) + ((uint64_t)team * NR + j) * p.nv2, (c0 + k * NT) * XD + h, ga[j][k][h]);
+      }
   {
     double w[2] = {fs, dx2};
     fs_block_reduce<2, NW>(w, s_scr);

@@ -194,7 +194,7 @@ int fh_init(fh_ctx* ctx, double* scalars);
 /* The whole set-up of a solve in one call (fasta/__init__.py:100-113 Lipschitz probes + :135-137 initial pass): with the two probes
  * in FH_VEC_T0 / FH_VEC_T1 and x0 in FH_VEC_X0 it leaves the state fh_init leaves and returns fh_init's scalars plus
  * FH_S_DG2 = ||A^H grad f(A T0) - A^H grad f(A T1)||^2 and FH_S_DX2 = ||T0 - T1||^2 (L = sqrt of their quotient, :110).
- * FH_VEC_T2 / FH_VEC_T3 are scratch afterwards.  A dense float64 least-squares operator with n <= 65536 on a single-device context
+ * FH_VEC_T2 / FH_VEC_T3 are scratch afterwards.  A dense least-squares operator with n <= 65536 (either storage) on a single-device context
  * is read ONCE for the whole set-up (csrc/fh_setup.h: two dot products and two rank-1 updates per row buffer -- x0, and the probes'
  * difference, since grad(T0) - grad(T1) = A^T A (T0 - T1) there); ROW BLOCKS (a multi-device context, a rank with a communicator) read
  * their block once each and sum the two gradients, the loss sums and the timeout words in one exchange -- a rank first settles the decision

@@ -98,10 +98,45 @@ def test_one_read_of_A_serves_the_two_probes_and_the_initial_pass(m, n, loss="ls
         op.close()
 
 
-@pytest.mark.parametrize("m,n,storage,loss", [(40, 100000, "f64", "lsq"), (30, 200000, "f64", "lsq"), (300, 16384, "f32", "lsq"), (96, 160, "f64", "lsq"),
+@pytest.mark.parametrize("m,n", [(300, 16384), (2100, 8192), (4300, 2000), (9000, 1000), (600, 30000), (150, 65536), (37, 65536), (260, 50000)])
+def test_float32_storage_takes_one_read_of_A_for_the_set_up(m, n):
+    """Round 6: k_setup_dense<..., F32 = 1> -- four-column pieces, at most four per lane (two right-hand sides cost 16 accumulator registers per
+    piece), teams of 1-16 members, n <= 65536: ONE read of the float32 matrix instead of three.  Against the three passes on the same (rounded)
+    matrix: rtol 1e-11 (other team shapes than the step kernel's, so not bit for bit), and against NumPy on A.astype(float32)."""
+    rng = np.random.RandomState(m * 3 + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    A32 = A.astype(np.float32).astype(np.float64)
+    op = fa.DenseMatrixMap(A, storage="f32")
+    try:
+        c = op.ctx
+        assert c.fused_supported() == 1
+        p1, p2, x0 = _load(c, rng, m, n, "lsq")
+        want = _three_pass(c, n, m)
+        for which, v in ((hip.VEC_T2, np.zeros(n)), (hip.VEC_T3, np.zeros(n))):
+            c.set_vector(which, v)
+        c.set_vector(hip.VEC_X0, x0)
+        got = _one_call(c, n, m)
+        assert want["one_pass_launches"] == 3 and got["one_pass_launches"] == 1
+        for key in ("g0", "z"):
+            np.testing.assert_allclose(got[key], want[key], rtol=1e-11, atol=1e-13 * np.abs(want[key]).max(), err_msg=key)
+        np.testing.assert_allclose([got["s"][k] for k in (hip.S_GSUM, hip.S_GMAX, hip.S_FSQ)], [want["s"][k] for k in (hip.S_GSUM, hip.S_GMAX, hip.S_FSQ)], rtol=1e-12)
+        b = c.get_vector(hip.VEC_B, m)
+        np.testing.assert_allclose(got["s"][hip.S_FSQ], np.sum((A32 @ x0 - b) ** 2), rtol=1e-11)
+        np.testing.assert_allclose(got["t2"], A32.T @ (A32 @ (p1 - p2)), rtol=1e-9, atol=1e-12 * np.abs(want["t2"]).max())
+        np.testing.assert_allclose(got["g0"], A32.T @ (A32 @ x0 - b), rtol=1e-9, atol=1e-12 * np.abs(want["g0"]).max())
+        np.testing.assert_allclose([got["dg"], got["dx"]], [want["dg"], want["dx"]], rtol=1e-12)
+        s1 = c.step(0.3)
+        c.set_vector(hip.VEC_X0, x0)
+        c.init()
+        np.testing.assert_allclose(c.step(0.3)[:14], s1[:14], rtol=1e-9, atol=1e-13)
+    finally:
+        op.close()
+
+
+@pytest.mark.parametrize("m,n,storage,loss", [(40, 100000, "f64", "lsq"), (30, 200000, "f64", "lsq"), (64, 100000, "f32", "lsq"), (96, 160, "f64", "lsq"),
                                                (64, 4096, "f64", "lsq"), (600, 16384, "f64", "logistic"), (2100, 4096, "f64", "logistic")])
 def test_shapes_without_a_one_read_kernel_take_the_three_passes_inside_the_call(m, n, storage, loss):
-    """rows wider than 65536 columns, float32 storage, the logistic loss (its gradient is not linear in x: no difference trick), matrices
+    """rows wider than 65536 columns (either storage), the logistic loss (its gradient is not linear in x: no difference trick), matrices
     too small for the one-pass kernel to pay: fh_setup is the three passes, with their results bit for bit."""
     rng = np.random.RandomState(n)
     A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
