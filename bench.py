@@ -431,7 +431,7 @@ def pmc_traffic(kernel_name):
 def fused_kernel_name(n, storage, tuning, ncu):
     """The one-pass instantiation fh_step launches for rows of n columns, spelled as rocprofv3 spells it."""
     from fasta_python_amd import hip
-    (ppt, pipe, team, xlds, nbo), inst = hip.fused_shape(n, storage, tuning.get(hip.TUNE_FUSED_VARIANT, 2) & 0xFFFF, ncu)
+    (ppt, pipe, team, xlds, nbo), inst = hip.fused_shape(n, storage, tuning.get(hip.TUNE_FUSED_VARIANT, 2 | 32) & 0xFFFF, ncu)
     return f"void k_fused_dense<{ppt}, 1, {pipe}, {team}, {xlds}, {nbo}, {1 if storage == 'f32' else 0}>(FusedP)" if inst else None
 
 

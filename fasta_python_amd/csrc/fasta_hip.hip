@@ -357,6 +357,9 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
       c->run_chain_on = value ? 1 : 0; return 0;
     case FH_TUNE_SEQ_POLL:
       c->seq_poll = value ? 1 : 0; return 0;
+    case FH_TUNE_ADJ_CYCLIC:
+      if (value < 0 || value > 2) return fail(FH_E_ARG, "ADJ_CYCLIC must be 0 (auto), 1 (on) or 2 (off)");
+      c->adj_cyclic = (int)value; return 0;
     case FH_TUNE_RUN_MAX_N:
       if (value < 0 || value > 7168) return fail(FH_E_ARG, "RUN_MAX_N must be in [0, 7168] (0 = the measured default; 7168 = the widest row fh_run has a kernel for)");
       c->run_max_n = (int)value; return 0;
@@ -706,7 +709,9 @@ static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
   HIP_TRY(hipMemsetAsync(c->counters + CNT_FUSED_BAR, 0, 8 * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->gridbar, 0, 2 * GB_WORDS * sizeof(unsigned), c->stream));
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
-  p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
+  // (rows dealt cyclically -- bit 32, the step kernel's default: 65536^2 float64 4.98-5.01 ms wherever the matrix lies, blocked 4.95-5.32; the float32 shapes
+  // are faster blocked, 4.39 vs 4.69 ms: profiles/r06_placement.txt)
+  p.variant = (c->fused_variant & ~(c->f32 ? 32 : 0)) | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);
   p.pack = sharded ? c->T[2] + c->nv : nullptr;     // (slack behind every n-side vector: alloc_vectors)
   t_begin(c, FH_K_FUSED);

@@ -196,6 +196,7 @@ struct AdjP {
   uint32_t m;           // logical rows
   uint32_t slab_rows;   // rows per slab (multiple of 8, <= ADJ_MAX_SLAB)
   uint32_t nslab, ncc;
+  uint32_t cyclic;      // != 0: slab s takes rows s, s + nslab, s + 2 nslab, ... (all slabs stream ONE window of the matrix); 0: rows [s * slab_rows, + slab_rows)
   const double* z; const double* zacc0; const double* b;
   int sub_b;            // r = grad f(z) (z - b for least squares), else r = z
   int loss;             // LOSS_LSQ / LOSS_LOGISTIC
@@ -247,17 +248,21 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
   __shared__ __attribute__((aligned(16))) unsigned s_flag[4];
   const uint32_t tid = threadIdx.x;
   const uint32_t cc = blockIdx.x % p.ncc, slab = blockIdx.x / p.ncc;
-  const uint32_t row0 = slab * p.slab_rows;
-  const uint32_t rows = min(p.slab_rows, p.mp - row0);
+  // rows of this slab: a contiguous block (default), or dealt cyclically over the slabs (FH_TUNE_ADJ_CYCLIC; what the one-pass kernel does by default since
+  // round 6 -- here measured mixed: profiles/r06_placement.txt)
+  const uint32_t row0 = p.cyclic ? slab : slab * p.slab_rows;
+  const uint32_t rstep = p.cyclic ? p.nslab : 1u;
+  const uint32_t rows = p.cyclic ? (slab < p.mp ? (p.mp - slab + p.nslab - 1u) / p.nslab : 0u) : min(p.slab_rows, p.mp - row0);
 
   // ---- stage the slab's residual r = z1' - b in LDS (z1' = extrapolated z when accelerating) ----
   double fs = 0.0;
   for (uint32_t i = tid; i < rows; i += FH_WG) {
-    double zv = p.z[row0 + i];
-    if (p.accel) zv = extrapolate(zv, p.zacc0[row0 + i], p.coef);
-    const double rv = p.sub_b ? loss_grad(zv, p.b[row0 + i], p.loss) : zv;
+    const uint32_t gr = row0 + i * rstep;
+    double zv = p.z[gr];
+    if (p.accel) zv = extrapolate(zv, p.zacc0[gr], p.coef);
+    const double rv = p.sub_b ? loss_grad(zv, p.b[gr], p.loss) : zv;
     s_r[i] = rv;
-    if (row0 + i < p.m) fs += p.sub_b ? loss_term(zv, p.b[row0 + i], p.loss) : zv * zv;
+    if (gr < p.m) fs += p.sub_b ? loss_term(zv, p.b[gr], p.loss) : zv * zv;
   }
   __syncthreads();
 
@@ -271,12 +276,13 @@ __global__ __launch_bounds__(FH_WG) void k_adj_dense(const AdjP p) {
     for (int e = 0; e < XD; ++e) acc[j][e] = (d2){0.0, 0.0};
   }
   const PT* Ab = reinterpret_cast<const PT*>(p.A) + (uint64_t)row0 * p.ld2;
+  const uint64_t astep = (uint64_t)rstep * p.ld2;
 #pragma unroll 4
   for (uint32_t i = 0; i < rows; ++i) {
     const double rv = s_r[i];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) piece_axpy(load_stream<NT>(Ab + col[j]), rv, acc[j]);
-    Ab += p.ld2;
+    Ab += astep;
   }
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {

@@ -161,6 +161,7 @@ struct fh_ctx {
   long long fwd_cap = 0;     // 0 = auto (4 workgroups per CU, grid-stride over row groups)
   int adj_slab = 0;          // 0 = auto
   int adj_cpt = 0;           // 0 = auto
+  int adj_cyclic = 0;        // 0 = auto = 2 = contiguous slabs, 1 = rows dealt cyclically to the slabs (A/B)
   int ld_pad = 0;
   int nt_loads = 1;
   // stencil defaults measured on MI355X at 8192^2 (profiles/r01_tune_tv.txt): plain (not nt) accesses,
@@ -173,7 +174,10 @@ struct fh_ctx {
   int tv_slots = 0;          // FH_TUNE_TV_SLOTS: persistent one-pass sweep, workgroups per CU (0 = one workgroup per chunk)
   int tv_ring = 0;           // FH_TUNE_TV_RING: LDS-DMA trip ring of the one-pass sweep (0 = auto, 1 = off, 2 / 3 = slots per wave)
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
-  int fused_variant = 2;     // team members 32 blocks apart (one XCD): best in profiles/r01b_tune_fused.txt
+  int fused_variant = 2 | 32;   // 2: team members 32 blocks apart (one XCD), best in profiles/r01b_tune_fused.txt; 32 (round 6): rows dealt cyclically to the teams -- the
+                             // whole grid streams ONE window of nteams x (rows in flight) consecutive rows instead of nteams windows spread over the matrix: 1-2 % faster on a
+                             // well-placed matrix (65536^2: 4.76 vs 4.84-4.88 ms), 9 % at 20000 x 30000, and INSENSITIVE to where the allocator put the matrix (blocked: 5.2-5.45 ms
+                             // for a 32 GiB matrix that got the far part of the device's memory, cyclic 4.79-4.81; profiles/r06_placement.txt)
   int test_hooks = 0;        // FH_TUNE_TEST_HOOKS (csrc/fh_experimental.h): fault injection, set by the test-suite only
   int fused_min_rows = 16;   // use fewer teams when m is small: at least this many rows per team (scripts/probes/fused_small_m.py)
   // one-pass kernel hand-off slots: two arrays alternate between launches, each launch re-arms the other one in passing;
@@ -256,19 +260,22 @@ static int use_device(fh_ctx* c) {
 
 // ---- large frees and the allocations behind them -------------------------------------------------------------------------------------
 // The driver clears freed device memory in the background, ~30 ms per GiB on MI355X.  Meanwhile a read-only stream over OTHER memory runs
-// 0.7-3 % slow -- and a large allocation made while the clearing is still going on comes out 13-14 % slow FOR ITS WHOLE LIFETIME: 6 of 6
-// interleaved cycles of { 128 GiB freed, 32 GiB allocated at once, 300 steps } at 5.49-5.54 ms per step against 4.85-4.89 with the remedies
-// below (profiles/r06_alloc_settle.txt; round 5 had seen it once).  Two remedies, both PER DEVICE:
-//   1. re-use (deterministic: no clearing, no new mapping, no sleep): the matrix block (>= 1 GiB) a context gives up is not returned to the
-//      driver but kept -- one block per device -- and handed to the next matrix on that device that fits it and fills at least half of it;
-//      fh_release_cached() / fh_alloc_cache(0) return it to the driver.
-//   2. settle: a matrix that cannot be served that way is allocated only after the device's earlier large frees have presumably been cleared
-//      (35 ms per GiB behind the free); fh_alloc_settle(0) switches the wait off, fh_alloc_settle_waited reports what it has cost so far.
+// 0.7-3 % slow -- and a large allocation made while the clearing is still going on is mapped less favourably FOR ITS WHOLE LIFETIME.  What that costs
+// depends on the kernel's access pattern (round 6, profiles/r06_placement.txt): with the rows dealt to the teams in contiguous blocks (rounds 1-5) the
+// one-pass kernel ran 9-14 % slow on such a matrix (6 of 6 interleaved cycles: 5.49-5.54 against 4.85-4.89 ms per step, profiles/r06_alloc_settle.txt),
+// and just as slow on a matrix that simply got the far part of the device's memory; with the rows dealt cyclically (the default now: the whole grid
+// streams one window of the matrix) it does not care: 4.82-4.85 ms right behind a 128 GiB free, waited for or not (3 of 3).  What is left:
+//   1. re-use (deterministic: no clearing, no new mapping, no sleep; worth ~1 % and the allocation's time): the matrix block (>= 1 GiB) a context gives up
+//      is not returned to the driver but kept -- one block per device -- and handed to the next matrix on that device that fits it and fills at least
+//      half of it; fh_release_cached() / fh_alloc_cache(0) return it to the driver.
+//   2. settle (OFF by default since the cyclic dealing; fh_alloc_settle(1) for callers that run the blocked dealing or live on K-adj, which still
+//      depend on the mapping): a matrix that cannot be served by 1. is allocated only after the device's earlier large frees have presumably been
+//      cleared (35 ms per GiB behind the free); fh_alloc_settle_waited reports what it has cost so far.
 #include <mutex>
 #define FH_MAX_DEVICES 64
 static std::atomic<long long> g_clear_until_ns[FH_MAX_DEVICES];       // steady clock, per device
 static std::atomic<long long> g_settle_waited_ns{0};
-static std::atomic<int> g_settle_on{1};
+static std::atomic<int> g_settle_on{0};
 static std::atomic<int> g_cache_on{1};
 static std::atomic<unsigned long long> g_cache_hits{0};
 struct CachedBlock { double* p = nullptr; size_t bytes = 0; };

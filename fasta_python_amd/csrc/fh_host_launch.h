@@ -109,6 +109,9 @@ static int launch_adj_dense(fh_ctx* c, const AdjIO& io) {
   }
   p.slab_rows = slab;
   p.nslab = (uint32_t)((c->mp + slab - 1) / slab);
+  // K-adj keeps its contiguous slabs: dealt cyclically (FH_TUNE_ADJ_CYCLIC = 1) it is 1-14 % faster on some small and mid shapes but 6 % SLOWER at 65536^2 and not
+  // less dependent on where the matrix lies (its workgroups are not in lockstep as the one-pass kernel's teams are; profiles/r06_placement.txt)
+  p.cyclic = c->adj_cyclic == 1;
   if (p.ncc + CNT_ADJ_CC > (uint32_t)CNT_DIAG) return fail(FH_E_ARG, "too many column chunks (%u)", p.ncc);
   p.z = io.z; p.zacc0 = io.zacc0; p.b = c->b; p.sub_b = io.sub_b; p.loss = c->loss_kind; p.accel = io.accel; p.coef = io.coef;
   p.mode = io.mode; p.tau = io.tau;

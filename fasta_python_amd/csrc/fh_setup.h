@@ -40,7 +40,7 @@ struct SetupP {
   unsigned* bar;               // [1] final arrivals (zero on entry; the finaliser zeroes it again)
   unsigned* gbar;              // 2 x GB_WORDS words: the two-level grid barrier and final arrival (fh_device.h:grid_barrier2 / arrive_last2), zero on entry, zeroed again at the end
   unsigned* err;
-  int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls (as FusedP.variant)
+  int variant;                 // bit 2: team members nteams blocks apart (one XCD), bit 4: no sleep between polls, bit 32: rows dealt cyclically (as FusedP.variant)
   double* out;                 // scalar block: [S_FSQ] loss sum at x0, [S_DX2] ||x1 - x2||^2, [S_DG2] ||grad1 - grad2||^2, [15] timeout
   double* pack;                // optional (row blocks, round 6): 2 doubles behind g[0] -- this block's loss sum and its timeout word -- so that the ONE sum
                                // over the row blocks of A_k^T A_k d carries them along; g[0], g[2] then hold this block's PARTIAL sums and [S_DG2] is void
@@ -114,12 +114,15 @@ __global__ __launch_bounds__(NT, 1) void k_setup_dense(const SetupP p) {
   // piece k of this lane is piece c0 + k * NT of the row -- if it lies inside the member's range and inside the row
   auto piece_ok = [&](int k) { return tid + (uint32_t)k * NT < (uint32_t)(FH_WG * MPP) && c0 + (uint32_t)k * NT < p.ld2; };
 
-  // rows of this team: exactly k_fused_dense's blocked assignment
-  const uint32_t row_base = min(team * p.rows_per_team, p.mp);
+  // rows of this team: exactly k_fused_dense's assignment -- variant bit 32 (the default): dealt cyclically (t, t + nteams, ...), else a contiguous block
+  const bool blocked = (p.variant & 32) == 0;
+  const uint32_t row_base = blocked ? min(team * p.rows_per_team, p.mp) : team;
+  const uint32_t row_step = blocked ? 1u : p.nteams;
   const uint32_t r_begin = 0u;
-  const uint32_t r_end = min(row_base + p.rows_per_team, p.mp) - row_base;
+  const uint32_t r_end = blocked ? min(row_base + p.rows_per_team, p.mp) - row_base
+                                 : (team < p.mp ? (p.mp - team + p.nteams - 1u) / p.nteams : 0u);
   const uint32_t r_last = r_end - 1u;
-  auto grow = [&](uint32_t r) { return row_base + r; };
+  auto grow = [&](uint32_t r) { return row_base + r * row_step; };
   uint32_t pc[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) pc[k] = piece_ok(k) ? c0 + k * NT : p.ld2 - 1u;      // clamped: loads stay unconditional and in bounds

@@ -24,7 +24,7 @@ NSCALARS = 16
 K_FWD, K_ADJ, K_AUX, K_COMM, K_FUSED, K_HOST_ISSUE, K_LEVEL = range(7)
 (TUNE_FWD_ROWS, TUNE_FWD_GRID_CAP, TUNE_ADJ_SLAB_ROWS, TUNE_ADJ_CPT, TUNE_LD_PAD, TUNE_NT_LOADS,
  TUNE_TV_U, TUNE_TV_ROWS, TUNE_TV_NT, TUNE_FUSED_VARIANT, TUNE_TV_ZFREE, TUNE_TV_PIPE, TUNE_TV_XCD, TUNE_TV_LDS_PAD,
- TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS, TUNE_RUN_MAX_N, TUNE_SEQ_POLL, TUNE_RUN_CHAIN) = range(20)
+ TUNE_TV_RING, TUNE_TV_SLOTS, TUNE_FUSED_CUS, TUNE_RUN_MAX_N, TUNE_SEQ_POLL, TUNE_RUN_CHAIN, TUNE_ADJ_CYCLIC) = range(21)
 # keys 10, 13, 14, 15 (TUNE_TV_ZFREE / _LDS_PAD / _RING / _SLOTS) are NOT in include/fasta_hip.h: experimental forms of the stencil sweep,
 # accepted only by libfasta_hip_experimental.so (csrc/fh_experimental.h); the shipped library answers FH_E_ARG
 EXPERIMENTAL_KEYS = (TUNE_TV_ZFREE, TUNE_TV_LDS_PAD, TUNE_TV_RING, TUNE_TV_SLOTS)
@@ -215,7 +215,8 @@ def comm_version():
 
 def alloc_settle(enable=True):
     """Process-wide: wait with a large (>= 1 GiB) matrix allocation that no kept block serves until the device's earlier large frees have
-    been cleared by the driver (default on; see include/fasta_hip.h and profiles/r06_alloc_settle.txt)."""
+    been cleared by the driver (default OFF since the one-pass kernel deals its rows cyclically and no longer depends on the mapping; see
+    include/fasta_hip.h, profiles/r06_alloc_settle.txt and profiles/r06_placement.txt)."""
     lib = load_library()
     _check(lib, lib.fh_alloc_settle(1 if enable else 0))
 

@@ -100,7 +100,7 @@ enum fh_tuning_key {
                                 one-pass kernels; the z-free one-pass sweep never loads non-temporally: its halo columns and rows are
                                 re-read through L2), 2 = non-temporal stores (the z-free sweep's default), 3 = plain accesses      */
   FH_TUNE_FUSED_VARIANT = 9, /* fused one-pass kernel: scheduling variant bits (see csrc/fh_fused.h: 2 = team members on one XCD, 4 = no
-                                sleep between polls, 8 / 16 = A/B team shapes, 32 = rows dealt cyclically); other bits are FH_E_ARG  */
+                                sleep between polls, 8 / 16 = A/B team shapes, 32 = rows dealt cyclically; default 2 | 32); other bits are FH_E_ARG */
   /* key 10 (the round-1 one-pass stencil kernels that stream z) is only present in -DFH_EXPERIMENTAL builds                    */
   FH_TUNE_TV_PIPE = 11,      /* z-free one-pass stencil sweep: 1 = load a trip of FH_TUNE_TV_U rows, consume it; 3 (2 is taken as 3) = three
                                 rotating trip buffers (two trips of loads stay in flight behind the one being consumed); 0 = auto   */
@@ -116,6 +116,9 @@ enum fh_tuning_key {
                                 separable prox: max_steps one-pass launches enqueued back to back, step size and buffer roles from a device state
                                 block, the loop's controller in each launch's finaliser).  Opt-in: measured equal to the host-side loop
                                 (profiles/r06_chain.txt) -- the gap between launches disappears, the launches grow by as much             */
+  FH_TUNE_ADJ_CYCLIC = 20,   /* K-adj: 1 = the rows are dealt cyclically to the slabs (slab s: rows s, s + nslab, ...), as bit 32 of FH_TUNE_FUSED_VARIANT does for
+                                the one-pass kernel; 0 = auto = 2 = contiguous slabs.  Measured mixed (faster on small and mid shapes, 6 % slower at
+                                65536^2; profiles/r06_placement.txt), so it stays an A/B switch                                                   */
   FH_TUNE_SEQ_POLL = 18,     /* 1 (default): a single-device step waits for its scalar block by the sequence number the launch writes behind
                                 it into host-mapped memory (~5 us sooner than the launch's completion signal); 0: hipStreamSynchronize (A/B)  */
   FH_TUNE_FUSED_CUS = 16     /* dense one-pass kernel: launch it on at most this many CUs (one workgroup each; 0 = every CU the device
@@ -336,13 +339,16 @@ int fh_comm_init(fh_ctx* ctx, int nranks, int rank, const void* id128);
 int fh_comm_count(fh_ctx* ctx, int* nranks);
 int fh_comm_destroy(fh_ctx* ctx);
 /* Large frees and the allocations behind them.  The driver clears freed device memory in the background (~30 ms per GiB on MI355X); a large
- * allocation made meanwhile comes out 13-14 % slow for its whole lifetime (profiles/r06_alloc_settle.txt: 6 of 6 cycles).  Two remedies, per device:
+ * allocation made meanwhile is mapped less favourably for its whole lifetime.  The one-pass kernel of rounds 1-5 (rows dealt to the teams in blocks) ran
+ * 9-14 % slow on such a matrix (profiles/r06_alloc_settle.txt: 6 of 6 cycles); with the rows dealt cyclically (default since round 6) it does not care
+ * (profiles/r06_placement.txt: 3 of 3).  Per device:
  *   - the matrix block (>= 1 GiB) a context gives up (fh_destroy, a new fh_set_matrix / fh_generate_matrix / fh_set_stencil) is KEPT, one block
  *     per device, and handed to the next matrix on that device that fits it and fills at least half of it: no clearing, no new mapping, no
  *     waiting.  The memory stays allocated until then: fh_release_cached(device | -1 = all) returns it to the driver, fh_alloc_cache(0)
  *     switches the keeping off (and releases), fh_alloc_cache_hits counts the re-uses;
- *   - a matrix of >= 1 GiB that no kept block serves is allocated only after the device's earlier large frees have presumably been cleared
- *     (35 ms per GiB behind the free): fh_alloc_settle(0) switches that wait off, fh_alloc_settle_waited returns the seconds spent in it.   */
+ *   - fh_alloc_settle(1) (default 0 since the cyclic dealing): a matrix of >= 1 GiB that no kept block serves is allocated only after the device's
+ *     earlier large frees have presumably been cleared (35 ms per GiB behind the free) -- for callers that select the blocked dealing or live on the
+ *     two-launch path, whose K-adj still depends on the mapping; fh_alloc_settle_waited returns the seconds spent in it.                     */
 int fh_alloc_settle(int enable);
 int fh_alloc_settle_waited(double* seconds);
 int fh_alloc_cache(int enable);

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 out=$(mktemp -d)
 for part in 0 1 2 3; do python scripts/loop_spills.py fh_fused_part.hip k_fused_dense -DFH_PART=$part > $out/fused$part.txt 2>&1 & done
-for part in 0 1; do python scripts/loop_spills.py fh_setup_part.hip k_setup_dense -DFH_PART=$part > $out/setup$part.txt 2>&1 & done
+for part in 0 1 2; do python scripts/loop_spills.py fh_setup_part.hip k_setup_dense -DFH_PART=$part > $out/setup$part.txt 2>&1 & done
 wait
 python scripts/loop_spills.py fasta_hip.hip "k_run_dense|k_tv_onepass|k_fwd_dense|k_adj_dense" > $out/host.txt 2>&1
 cat $out/fused?.txt $out/setup?.txt $out/host.txt

@@ -10,7 +10,12 @@ probe = ctypes.CDLL(lib)
 for name in list(hip.SIGNATURES):
     if not hasattr(probe, name):
         del hip.SIGNATURES[name]            # an older build lacks newer entry points
-hip.load_library(lib)
+if hasattr(probe, "fh_abi_sizes"):
+    hip.load_library(lib)
+else:                                       # a build from before the layout check: bind what it has (the probe below passes no struct by pointer)
+    for name, (res, args) in hip.SIGNATURES.items():
+        fn = getattr(probe, name); fn.restype, fn.argtypes = res, args
+    hip._lib = probe
 import fasta_python_amd as fa
 from fasta_python_amd import synthetic
 m = n

@@ -50,7 +50,7 @@ def test_struct_layouts_and_constants_of_the_loop_entry_points_match_the_library
         assert names == [f[0] for f in mirror._fields_], struct
     for cname, value in (("FH_LAUNCH_SEPARATE", hip.LAUNCH_SEPARATE), ("FH_LAUNCH_ONEPASS_ALWAYS", hip.LAUNCH_ONEPASS_ALWAYS),
                          ("FH_LAUNCH_ONEPASS_SPECULATIVE", hip.LAUNCH_ONEPASS_SPECULATIVE), ("FH_LAUNCH_PAIR", hip.LAUNCH_PAIR),
-                         ("FH_TUNE_RUN_MAX_N", hip.TUNE_RUN_MAX_N), ("FH_TUNE_SEQ_POLL", hip.TUNE_SEQ_POLL), ("FH_TUNE_RUN_CHAIN", hip.TUNE_RUN_CHAIN),
+                         ("FH_TUNE_RUN_MAX_N", hip.TUNE_RUN_MAX_N), ("FH_TUNE_SEQ_POLL", hip.TUNE_SEQ_POLL), ("FH_TUNE_RUN_CHAIN", hip.TUNE_RUN_CHAIN), ("FH_TUNE_ADJ_CYCLIC", hip.TUNE_ADJ_CYCLIC),
                          ("FH_TUNE_FUSED_CUS", hip.TUNE_FUSED_CUS)):
         m = re.search(cname + r"\s*=\s*(\d+)", text)
         assert m and int(m.group(1)) == value, cname

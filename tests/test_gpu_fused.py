@@ -24,7 +24,7 @@ def _state(op, b, mu, x0, prox=hip.PROX_SHRINK):
 # variant bits: 2 = team members on one XCD (default), 0 = consecutive blocks, 8 = n=65536 as 8 members x 16 pieces with the
 # exchange in line (default there: 16 members x 8 pieces, posts two rows ahead); n in (65536, 131072] runs 16 members x 9..16 pieces
 # with the x slice in LDS, posting one row ahead (variant bit 16: the round-1 shape, 16 x 16 in line)
-@pytest.mark.parametrize("variant", [2, 0, 10, 18])
+@pytest.mark.parametrize("variant", [34, 2, 0, 10, 18, 42, 50])      # 34 = the default (2: members on one XCD, 32: rows dealt cyclically)
 @pytest.mark.parametrize("m,n", [(1, 4096), (37, 4096), (300, 4096), (4097, 4096), (500, 8192), (200, 16384), (130, 32768),
                                  (70, 65536), (40, 131072),
                                  # ragged n: the next shape up with the surplus lanes masked

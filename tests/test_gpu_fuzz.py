@@ -39,7 +39,9 @@ def _same(got, want, rtol=1e-6, rtol_steps=None):
         np.testing.assert_allclose(getattr(got, f)[:k], getattr(want, f)[:k], rtol=r, atol=1e-14, err_msg=f)
     if want.objectives is not None:
         np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=rtol, atol=1e-14)
-    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9)
+    # the solution after up to 60 iterations: rtol 1e-5 per element, with an absolute floor of 1e-6 of the vector's largest entry -- an entry that the
+    # prox has pulled close to zero carries the rounding of the whole column sum (order of summation: teams x rows), not 1e-5 of ITS OWN size
+    np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-9 + 1e-6 * float(np.max(np.abs(want.solution), initial=0.0)))
     assert got.residuals.shape == want.residuals.shape and got.times.shape == want.times.shape     # untruncated histories
 
 
