@@ -946,7 +946,9 @@ def main(argv=None):
                      "stream_read_ceiling_GB/s": max(ceilings.values()),
                      "stream_read_GB/s_by_workgroups_per_cu": ceilings,
                      "stream_read_probe": "k_stream_probe<16,1> over the same device copy of A: one or two persistent workgroups per CU (best of both), three rotating "
-                                          "register buffers of 16 non-temporal 16-byte loads per lane (32 loads in flight), loads + adds only",
+                                          "register buffers of 16 non-temporal 16-byte loads per lane (32 loads in flight), loads + adds only.  A reference stream, not a bound: "
+                                          "its workgroups run free, the one-pass kernel's teams advance in lockstep over one window of rows (rows dealt cyclically, round 6) "
+                                          "and read the same bytes 1-1.5 % faster than this probe",
                      "per_kernel": main_r["per_kernel"],
                      "loop_GB/s_wallclock": main_r["loop_GB/s_wallclock"],
                      "vs_two_pass_model": main_r["vs_two_pass_model"],
