@@ -366,6 +366,7 @@ static int set_tuning_one(fh_ctx* c, int key, long long value) {
     case FH_TUNE_FUSED_VARIANT:
       // (bits 64 / 128 were test hooks until round 4: a caller's variant word must not be able to switch the one-pass kernel off)
       if (value & 0xFFC1) return fail(FH_E_ARG, "FUSED_VARIANT: only the scheduling bits 2, 4, 8, 16, 32 are defined (got 0x%llx)", (unsigned long long)(value & 0xFFFF));
+      c->fused_variant_auto = false;
       c->fused_variant = (int)(value & 0xFFFF);      // bits: see FusedP.variant (csrc/fh_fused.h) and fused_shape() below (8, 16: A/B shapes)
       if (value >> 16) c->fused_min_rows = (int)(value >> 16) == 0xFFFF ? 0 : (int)(value >> 16);   // high half: rows-per-team floor (0xFFFF = none)
       return 0;
@@ -711,7 +712,7 @@ static int launch_setup_dense(fh_ctx* c, bool* launched, bool sharded = false) {
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
   // (rows dealt cyclically -- bit 32, the step kernel's default: 65536^2 float64 4.98-5.01 ms wherever the matrix lies, blocked 4.95-5.32; the float32 shapes
   // are faster blocked, 4.39 vs 4.69 ms: profiles/r06_placement.txt)
-  p.variant = (c->fused_variant & ~(c->f32 ? 32 : 0)) | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
+  p.variant = (fused_variant_for(c, p.rows_per_team) & ~(c->f32 && c->fused_variant_auto ? 32 : 0)) | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);
   p.out = scalar_out(c);
   p.pack = sharded ? c->T[2] + c->nv : nullptr;     // (slack behind every n-side vector: alloc_vectors)
   t_begin(c, FH_K_FUSED);

@@ -174,6 +174,7 @@ struct fh_ctx {
   int tv_slots = 0;          // FH_TUNE_TV_SLOTS: persistent one-pass sweep, workgroups per CU (0 = one workgroup per chunk)
   int tv_ring = 0;           // FH_TUNE_TV_RING: LDS-DMA trip ring of the one-pass sweep (0 = auto, 1 = off, 2 / 3 = slots per wave)
   int tv_pipe = 0;           // FH_TUNE_TV_PIPE: rotating trip buffers of the one-pass sweep (0 = auto, 1 = burst, 2, 3)
+  bool fused_variant_auto = true;   // cleared by FH_TUNE_FUSED_VARIANT: the caller's word is taken as it is (fused_variant_for)
   int fused_variant = 2 | 32;   // 2: team members 32 blocks apart (one XCD), best in profiles/r01b_tune_fused.txt; 32 (round 6): rows dealt cyclically to the teams -- the
                              // whole grid streams ONE window of nteams x (rows in flight) consecutive rows instead of nteams windows spread over the matrix: 1-2 % faster on a
                              // well-placed matrix (65536^2: 4.76 vs 4.84-4.88 ms), 9 % at 20000 x 30000, and INSENSITIVE to where the allocator put the matrix (blocked: 5.2-5.45 ms

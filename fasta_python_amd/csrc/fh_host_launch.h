@@ -302,6 +302,16 @@ static int launch_adj_tv(fh_ctx* c, const AdjIO& io) {
 // FusedShape = the template key of k_fused_dense (PPT, PIPE, TEAM, XLDS, NBO) for a row of n columns: a pure function of
 // (n, row stride, storage, FH_TUNE_FUSED_VARIANT, #CUs), exported as fh_fused_shape so that it can be checked without a GPU.
 struct FusedShape { int ppt, team, pipe, xlds, nbo; };
+// The scheduling word a launch gets.  Rows are dealt cyclically (bit 32) where a team has at least 128 rows: below that the blocked dealing is as fast or
+// 1-4 % faster (8192^2, teams of 2 with 64 rows each: 0.112 against 0.114 ms; 4096 x 8192: 0.0705 / 0.0735), from 256 rows per team on the cyclic one
+// is 3-4 % faster on a well-placed matrix and up to 14 % on a badly placed one (profiles/r06_placement.txt) -- matrices of that size are small enough for
+// their placement not to matter.  A word set through FH_TUNE_FUSED_VARIANT is passed on unchanged.
+static int fused_variant_for(const fh_ctx* c, uint32_t rows_per_team) {
+  int v = c->fused_variant;
+  if (c->fused_variant_auto && rows_per_team < 128u) v &= ~32;
+  return v;
+}
+
 static FusedShape fused_shape_for(uint64_t n, uint64_t ld, int f32, int variant, int ncu) {
   const FusedShape none = {0, 0, 0, 0, 0};
   if (ld % 2 || n == 0) return none;
@@ -456,7 +466,7 @@ static int launch_fused_dense(fh_ctx* c, double tau, const FusedIO& io, const Ch
   }
   p.g1 = io.g1;
   p.bar = c->counters + CNT_FUSED_BAR; p.gbar = c->gridbar; p.err = c->counters + CNT_FUSED_ERR;
-  p.variant = c->fused_variant | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
+  p.variant = fused_variant_for(c, p.rows_per_team) | ((c->test_hooks & FH_HOOK_WITHHOLD_PARTIAL) ? 64 : 0);      // (bit 64 of FusedP.variant: the kernel's fault-injection switch)
   p.out = scalar_out(c);
   const ChainEntry* chain_entry = chain ? chain_lookup(sh, c->f32) : nullptr;
   if (chain && !chain_entry) return fail(FH_E_STATE, "chained one-pass launch: no instantiation for this shape (teams of 1 / 2 / 4 members, float64)");
