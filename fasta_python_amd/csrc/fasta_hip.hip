@@ -1226,7 +1226,7 @@ extern "C" int fh_run(fh_ctx* c, int max_steps, const fh_run_opts* o, fh_run_sta
   for (int q = 0; q < 5; ++q) p.nbuf[q] = nb[q];
   p.G[0] = c->G[0]; p.G[1] = c->G[1]; p.Z[0] = c->Z[0]; p.Z[1] = c->Z[1]; p.xhat = c->xhat; p.b = c->b;
   p.loss = c->loss_kind; p.prox_kind = c->prox_kind; p.mu = c->mu; p.lo = c->lo; p.hi = c->hi;
-  p.nt = c->nt_loads;
+  p.nt = nt_for(c);
   p.g_kind = c->prox_kind == FH_PROX_SHRINK ? 1 : 0;
   p.o.adaptive = o->adaptive; p.o.accelerate = o->accelerate; p.o.backtrack = o->backtrack; p.o.restart = o->restart;
   p.o.evaluate_objective = o->evaluate_objective; p.o.stop_rule = o->stop_rule; p.o.window = o->window; p.o.max_backtracks = o->max_backtracks;

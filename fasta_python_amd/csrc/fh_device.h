@@ -363,14 +363,20 @@ __device__ __forceinline__ bool publish_partials(double* slot, const double (&v)
 }
 
 // 16-byte streaming load of A.  NT=1 marks it non-temporal (read-once stream; keeps x0/g0 in L2).
+// (-DFH_PLAIN_LOADS: an A/B build whose streams all use the default cache policy -- make OUT=../libfasta_hip_plain.so BUILD=build_plain EXTRA=-DFH_PLAIN_LOADS)
+#ifdef FH_PLAIN_LOADS
+#define FH_NT_LOAD(p) (*(p))
+#else
+#define FH_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 template <int NT>
 __device__ __forceinline__ d2 load_stream(const d2* p) {
-  if (NT) return __builtin_nontemporal_load(p);
+  if (NT) return FH_NT_LOAD(p);
   return *p;
 }
 template <int NT>
 __device__ __forceinline__ f4 load_stream(const f4* p) {
-  if (NT) return __builtin_nontemporal_load(p);
+  if (NT) return FH_NT_LOAD(p);
   return *p;
 }
 

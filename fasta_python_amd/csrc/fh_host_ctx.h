@@ -163,7 +163,7 @@ struct fh_ctx {
   int adj_cpt = 0;           // 0 = auto
   int adj_cyclic = 0;        // 0 = auto = 2 = contiguous slabs, 1 = rows dealt cyclically to the slabs (A/B)
   int ld_pad = 0;
-  int nt_loads = 1;
+  int nt_loads = -1;         // K-fwd / K-adj stream A with non-temporal loads: 1 / 0, -1 = auto (nt_for below: plain loads for a matrix of at most 256 MiB)
   // stencil defaults measured on MI355X at 8192^2 (profiles/r01_tune_tv.txt): plain (not nt) accesses,
   // 8 rows in flight, 32 rows per workgroup for K-fwd and 128 for the read-only K-adj
   int tv_u = 0;              // 0 = auto: 8 for the kernels that stream z, 2 / 4 for the z-free one-pass sweeps (profiles/r02_tune_tv.txt)

@@ -16,13 +16,22 @@ static ProxP make_prox(fh_ctx* c, double tau) {
   return px;
 }
 
+// K-fwd / K-adj: non-temporal loads of A (+10 % on matrices that only stream through) -- except for a matrix of at most 256 MiB, the size of the device's
+// last-level cache, which the next launch finds there again if it was loaded with the default policy: 4096^2 K-adj 0.049 against 0.075 ms, 5120^2 0.063 / 0.088,
+// K-fwd 0.030 / 0.033; from 8192^2 (512 MiB) on the non-temporal form is the faster one again (profiles/r06_placement.txt, section 11).  The one-pass kernels
+// always load non-temporally (plain: +-3 % at these sizes, where their time is mostly fixed cost).
+static inline int nt_for(const fh_ctx* c) {
+  if (c->nt_loads >= 0) return c->nt_loads;
+  return (uint64_t)c->mp * c->ld * (c->f32 ? 4u : 8u) > ((uint64_t)256 << 20);
+}
+
 template <int R, int KIND>
 static void launch_fwd_rk(fh_ctx* c, const FwdP& p, unsigned grid) {
   if (c->f32) {                                   // float32 storage: non-temporal loads only, R = 4 or 8
     if constexpr (R == 16) k_fwd_dense<8, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
     else k_fwd_dense<R, 1, KIND, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   }
-  else if (c->nt_loads) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else if (nt_for(c)) k_fwd_dense<R, 1, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_fwd_dense<R, 0, KIND><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 template <int R>
@@ -79,7 +88,7 @@ static int launch_fwd_dense(fh_ctx* c, int mode, double tau, const double* x0, c
 template <int CPT>
 static void launch_adj_c(fh_ctx* c, const AdjP& p, unsigned grid) {
   if (c->f32) k_adj_dense<CPT, 1, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
-  else if (c->nt_loads) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
+  else if (nt_for(c)) k_adj_dense<CPT, 1><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
   else k_adj_dense<CPT, 0><<<dim3(grid), dim3(FH_WG), 0, c->stream>>>(p);
 }
 

@@ -93,7 +93,8 @@ enum fh_tuning_key {
   FH_TUNE_ADJ_SLAB_ROWS = 2, /* rows per K-adj slab (multiple of 8; 0 = auto)               */
   FH_TUNE_ADJ_CPT = 3,       /* 16-byte column pairs per thread in K-adj: 1, 2, 4 (0 = auto) */
   FH_TUNE_LD_PAD = 4,        /* extra doubles appended to each device row of A (multiple of 16; set before the matrix) */
-  FH_TUNE_NT_LOADS = 5,      /* 1 = stream A with non-temporal loads (default), 0 = default cache policy */
+  FH_TUNE_NT_LOADS = 5,      /* K-fwd / K-adj / the device loop: 1 = stream A with non-temporal loads, 0 = default cache policy; unset = auto: plain
+                                loads for a matrix of at most 256 MiB (it stays in the last-level cache between launches), non-temporal above  */
   FH_TUNE_TV_U = 6,          /* stencil kernels: rows of loads per trip and lane (2, 4, 8; 0 = auto)  */
   FH_TUNE_TV_ROWS = 7,       /* stencil kernels: image rows per workgroup (0 = auto)                 */
   FH_TUNE_TV_NT = 8,         /* stencil kernels: 0 = default, 1 = non-temporal loads and stores (two-launch kernels and the z-streaming

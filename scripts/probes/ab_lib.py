@@ -25,7 +25,7 @@ rng = np.random.RandomState(0)
 ctx.set_loss_lsq(rng.randn(m)); ctx.set_prox(hip.PROX_SHRINK, 0.02)
 ctx.set_vector(hip.VEC_X0, rng.randn(n) * 0.01)
 ctx.init()
-def timed(fn, kid, reps=8):
+def timed(fn, kid, reps=8 if n > 16384 else 200):
     fn()
     ctx.timing_reset(); ctx.timing_enable(True)
     for _ in range(reps):

@@ -16,6 +16,9 @@ if os.environ.get("FH_RUN_CHAIN") == "1":          # the chained form of fh_run 
     tuning[hip.TUNE_RUN_CHAIN] = 1
     tuning.pop(hip.TUNE_RUN_MAX_N)
     print("# FH_TUNE_RUN_CHAIN = 1, default window of the persistent launch: the device column is the chain of one-pass launches outside it")
+if os.environ.get("FH_NT_LOADS") in ("0", "1"):        # A/B: the device loop (and K-fwd / K-adj) with plain / non-temporal loads of A (the one-pass kernel has no plain form)
+    tuning[hip.TUNE_NT_LOADS] = int(os.environ["FH_NT_LOADS"])
+    print(f"# FH_TUNE_NT_LOADS = {tuning[hip.TUNE_NT_LOADS]}")
 if os.environ.get("FH_SEQ_POLL") == "0":          # A/B: wait for every launch with hipStreamSynchronize (rounds 1-5) instead of its sequence number
     tuning[hip.TUNE_SEQ_POLL] = 0
     print("# FH_TUNE_SEQ_POLL = 0: hipStreamSynchronize after every launch")
