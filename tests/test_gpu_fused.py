@@ -467,3 +467,39 @@ def test_two_capped_contexts_run_their_launches_at_the_same_time():
     finally:
         for op in ops:
             op.close()
+
+
+@pytest.mark.parametrize("m,n,expect", [(40000, 4096, "cyclic"),      # one member per team, 256 teams: 157 rows each
+                                        (20000, 8192, "cyclic"),      # two members, 128 teams: 157 rows each
+                                        (6000, 16384, "blocked"),     # four members, 64 teams: 94 rows each
+                                        (3000, 4096, "blocked")])     # 12 rows each
+def test_rows_are_dealt_cyclically_from_128_rows_per_team_on(m, n, expect):
+    """Round 6 (profiles/r06_placement.txt): team t of the one-pass kernel takes rows t, t + T, ... (FH_TUNE_FUSED_VARIANT bit 32) where a team has at least 128 rows,
+    a contiguous block below; a caller's word is passed on unchanged.  The dealing decides the order in which g1 = A^T r is summed, so the default must equal the explicit
+    word of the expected dealing BIT FOR BIT and the other one to rounding; both must equal the two-launch step and NumPy."""
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b, x0 = rng.randn(m), rng.randn(n) * 0.05
+    tau, mu = 0.4, 0.03
+    op = fa.DenseMatrixMap(A)
+    try:
+        ref = _pair_reference(op, b, mu, x0, tau, False)
+        c = _state(op, b, mu, x0)
+        default = c.step(tau)
+        _assert_step_matches(c, default, ref, n, m)
+        g_default, z_default = c.get_vector(hip.VEC_G1, n), c.get_vector(hip.VEC_Z, m)
+        got = {}
+        for name, word in (("cyclic", 2 | 32), ("blocked", 2)):
+            op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, word)
+            c = _state(op, b, mu, x0)
+            _assert_step_matches(c, c.step(tau), ref, n, m)
+            got[name] = c.get_vector(hip.VEC_G1, n)
+            assert np.array_equal(c.get_vector(hip.VEC_Z, m), z_default)          # z = A xp is a per-row result: the same whoever computes the row
+        other = "blocked" if expect == "cyclic" else "cyclic"
+        assert np.array_equal(g_default, got[expect])
+        assert not np.array_equal(got[expect], got[other])                        # (the two dealings do sum in different orders)
+        np.testing.assert_allclose(got[other], got[expect], rtol=1e-11, atol=1e-15)
+        xp = fo.shrink(x0 - tau * (A.T @ (A @ x0 - b)), tau * mu)
+        np.testing.assert_allclose(g_default, A.T @ (A @ xp - b), rtol=1e-10, atol=1e-14)
+    finally:
+        op.close()
