@@ -489,16 +489,18 @@ def test_rows_are_dealt_cyclically_from_128_rows_per_team_on(m, n, expect):
         _assert_step_matches(c, default, ref, n, m)
         g_default, z_default = c.get_vector(hip.VEC_G1, n), c.get_vector(hip.VEC_Z, m)
         got = {}
+        other = "blocked" if expect == "cyclic" else "cyclic"
         for name, word in (("cyclic", 2 | 32), ("blocked", 2)):
             op.ctx.set_tuning(hip.TUNE_FUSED_VARIANT, word)
+            ref_w = _pair_reference(op, b, mu, x0, tau, False)                    # (fh_init's gradient g0 comes from the one-pass kernel too: a reference per dealing)
             c = _state(op, b, mu, x0)
-            _assert_step_matches(c, c.step(tau), ref, n, m)
+            _assert_step_matches(c, c.step(tau), ref_w, n, m)
             got[name] = c.get_vector(hip.VEC_G1, n)
-            assert np.array_equal(c.get_vector(hip.VEC_Z, m), z_default)          # z = A xp is a per-row result: the same whoever computes the row
-        other = "blocked" if expect == "cyclic" else "cyclic"
+            if name == expect:
+                assert np.array_equal(c.get_vector(hip.VEC_Z, m), z_default)
         assert np.array_equal(g_default, got[expect])
         assert not np.array_equal(got[expect], got[other])                        # (the two dealings do sum in different orders)
-        np.testing.assert_allclose(got[other], got[expect], rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(got[other], got[expect], rtol=1e-9, atol=1e-13)
         xp = fo.shrink(x0 - tau * (A.T @ (A @ x0 - b)), tau * mu)
         np.testing.assert_allclose(g_default, A.T @ (A @ xp - b), rtol=1e-10, atol=1e-14)
     finally:
