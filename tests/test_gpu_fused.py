@@ -498,6 +498,9 @@ def test_rows_are_dealt_cyclically_from_128_rows_per_team_on(m, n, expect):
             got[name] = c.get_vector(hip.VEC_G1, n)
             if name == expect:
                 assert np.array_equal(c.get_vector(hip.VEC_Z, m), z_default)
+            ref_acc = _pair_reference(op, b, mu, x0, tau, True)                   # FISTA's extrapolation and restart dot under the same dealing
+            c = _state(op, b, mu, x0)
+            _assert_step_matches(c, c.step_accel(tau, 0.25, False), ref_acc, n, m)
         assert np.array_equal(g_default, got[expect])
         assert not np.array_equal(got[expect], got[other])                        # (the two dealings do sum in different orders)
         np.testing.assert_allclose(got[other], got[expect], rtol=1e-9, atol=1e-13)

@@ -49,7 +49,9 @@ def _load(c, rng, m, n, loss):
 
 # teams of 1, 2, 4, 8, 16 members (n <= 4096, 8192, 16384, 32768, 65536), full and ragged widths, few and many rows per team
 SHAPES = [(2100, 4096), (4200, 2000), (9000, 1000), (1100, 8192), (1500, 6000), (600, 16384), (700, 12000), (300, 32768), (330, 20000),
-          (150, 65536), (260, 50000), (37, 65536), (1, 40000)]
+          (150, 65536), (260, 50000), (37, 65536), (1, 40000),
+          # at least 128 rows per team: rows dealt cyclically (round 6), in the set-up kernel as in the step kernel
+          (40000, 4096), (20000, 8192), (12000, 16384), (3000, 65536)]
 
 
 @pytest.mark.parametrize("m,n", SHAPES)
