@@ -248,3 +248,18 @@ def test_random_shapes_modes_and_launch_lengths_with_the_loop_on_the_device(seed
         np.testing.assert_allclose(got.objectives[:k + 1], want.objectives[:k + 1], rtol=1e-5, atol=1e-14)
     np.testing.assert_allclose(got.solution, want.solution, rtol=1e-5, atol=1e-8)
     assert got.residuals.shape == want.residuals.shape and got.times.shape == want.times.shape
+
+
+@pytest.mark.parametrize("kind,adaptive,accelerate", [("shrink", True, False), ("shrink", False, True), ("shrink", False, False),
+                                                      ("nonneg", True, False), ("nonneg", False, True), ("l1ball", True, False)])
+@pytest.mark.parametrize("m,n", [(40000, 2048), (20000, 8192)])       # 256 teams of one / 128 teams of two members, 157 rows per team
+def test_tall_problems_whose_rows_are_dealt_cyclically(m, n, kind, adaptive, accelerate):
+    """Most cases above have few rows per team, i.e. the blocked dealing; from 128 rows per team on the one-pass kernel deals its rows cyclically
+    (round 6, profiles/r06_placement.txt).  Whole solves in every mode against the oracle loop at such shapes, every iteration."""
+    rng = np.random.RandomState(m + n)
+    A = rng.randn(m, n) / (np.sqrt(m) + np.sqrt(n))
+    b = rng.randn(m)
+    x0 = rng.randn(n) * 0.1
+    opts = dict(adaptive=adaptive, accelerate=accelerate, max_iters=30, tolerance=1e-8, evaluate_objective=True, window=5)
+    got, want = _pair(A, b, kind, 0.05, x0, opts, 11)
+    _same(got, want)
